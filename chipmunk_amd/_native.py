@@ -1,0 +1,42 @@
+"""ctypes view of the C ABI (``include/chipmunk_hip.h``) -- used by the ABI tests and by code that wants to call the
+kernels without going through ``torch.ops``.  Loading fails loudly: there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libchipmunk_hip.so")
+
+# every symbol include/chipmunk_hip.h declares (tests/test_abi.py checks this list against the header)
+SYMBOLS = [
+    "chipmunk_last_error", "chipmunk_abi_version",
+    "chipmunk_csp_attn", "chipmunk_csp_128_attn", "chipmunk_dense_attn", "chipmunk_dense_colsum_attn",
+    "chipmunk_csp_mlp_mm1", "chipmunk_csp_mlp_mm2_and_scatter_add", "chipmunk_csp_scatter_add", "chipmunk_csp_mlp_mm2",
+    "chipmunk_topk_indices", "chipmunk_mask_to_indices", "chipmunk_packed_mask_to_indices", "chipmunk_copy_indices",
+    "chipmunk_bitpack", "chipmunk_bitunpack",
+]
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m chipmunk_amd.build` (hipcc --offload-arch=gfx950). "
+                "chipmunk_amd has no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.chipmunk_last_error.restype = ctypes.c_char_p
+        _lib.chipmunk_abi_version.restype = ctypes.c_int
+    return _lib
+
+
+def last_error() -> str:
+    return lib().chipmunk_last_error().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what}: {last_error()}")

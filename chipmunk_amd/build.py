@@ -1,0 +1,70 @@
+"""In-tree build of the two native artefacts (no JIT cache, so the built files travel with the tree):
+
+* ``chipmunk_amd/lib/libchipmunk_hip.so`` -- the HIP kernels + C ABI (``include/chipmunk_hip.h``), hipcc, gfx950 only;
+* ``chipmunk_amd/cuda*.so``               -- the PyTorch operator registry over that ABI (module ``chipmunk_amd.cuda``).
+
+The reference builds one ``CUDAExtension('chipmunk.cuda')`` for sm_90a (reference setup.py:101-143).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "csrc")
+LIBDIR = os.path.join(ROOT, "lib")
+HIP_LIB = os.path.join(LIBDIR, "libchipmunk_hip.so")
+TORCH_EXT = os.path.join(ROOT, "cuda.so")
+HIP_SOURCES = ["attn.hip", "mlp.hip", "indexed_io.hip", "capi.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip_lib(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
+    if force or _newer(HIP_LIB, deps):
+        os.makedirs(LIBDIR, exist_ok=True)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    import torch
+    from torch.utils import cpp_extension
+
+    src = os.path.join(CSRC, "torch_registry.cpp")
+    if not (force or _newer(TORCH_EXT, [src, os.path.join(ROOT, "..", "include", "chipmunk_hip.h")])):
+        return TORCH_EXT
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    incs = cpp_extension.include_paths("cuda") + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{i}" for i in incs]
+    cmd += [src, "-o", TORCH_EXT, f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip",
+            f"-L{LIBDIR}", "-lchipmunk_hip", "-Wl,-rpath,$ORIGIN/lib", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TORCH_EXT
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip_lib(force, verbose)
+    build_torch_ext(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

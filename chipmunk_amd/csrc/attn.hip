@@ -1,0 +1,413 @@
+// Column-sparse / dense attention for gfx950 (MI355X), one templated kernel behind four C-ABI entry points.
+//
+// Replaces the reference's four Hopper kernels (csrc/attn/{csp_attn,csp_128_attn,dense_attn,dense_colsum_attn}.cu).
+// Nothing of their structure (TMA, WGMMA, producer/consumer warpgroups, 112/128-row KV tiles) is kept; the design is
+// CDNA4-first:
+//   * one workgroup = one (batch, head, 192-query group) = 4 waves x 48 query rows, one wave per SIMD,
+//     two workgroups per CU (LDS 64.5 KiB each) so every SIMD holds two waves;
+//   * "swapped" QK^T: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16, so a lane owns ONE query column and its softmax
+//     statistics (running max, partial sum, rescale factor) are lane-local scalars;
+//   * P^T (bf16) is consumed straight from registers as the B operand of O^T += V^T.P^T -- the k-order permutation of
+//     the accumulator layout is absorbed by the order in which V^T fragments are fetched (ds_read_b64_tr_b16);
+//   * K/V rows (256 B each) are gathered HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): the per-lane global
+//     address does the gather, the XOR swizzle of the 16-byte chunk index is applied on the SOURCE address so the
+//     lane-linear LDS image is bank-conflict-free for ds_read_b128 (K) and ds_read_b64_tr_b16 (V);
+//   * 2-deep LDS ring, gather indices prefetched one tile further ahead, one barrier per 64-key tile;
+//   * XCD-aware block remap: each XCD walks a contiguous range of (head, group) so one head's K/V stays in its L2.
+#include "common.h"
+
+namespace {
+
+constexpr int QG = 192;   // query rows per group == per workgroup (reference mbm = 192, modules/attn.py:95-96)
+constexpr int QW = 48;    // query rows per wave
+constexpr int KVT = 64;   // gathered keys per LDS tile
+constexpr int HD = 128;   // head dim (reference: "Head dimension must be 128", csp_attn.cu:381-383)
+constexpr int TILE_BYTES = KVT * HD * 2;  // 16 KiB
+constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;  // csp_128_attn.cu:307
+constexpr int ATTN_LDS_BYTES = 4 * TILE_BYTES + 2 * KVT * 4;
+
+struct AttnParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    int64_t qs[3], ks[3], vs[3], os[3];
+    const int32_t *indices, *counts;
+    float *l_out;
+    const float *p_in;
+    uint16_t *cs;
+    int cs_stride;
+    int B, H, Nq, Nk, G, idx_stride;
+    float o_scale;
+};
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Kl = smem;
+    unsigned char *Vl = smem + 2 * TILE_BYTES;
+    float *cs_acc = (float *)(smem + 4 * TILE_BYTES);  // [2][KVT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wid / p.G, g = wid - bh * p.G;
+    const int b = bh / p.H, h = bh - b * p.H;
+
+    const int count = GATHER ? p.counts[(int64_t)bh * p.G + g] : p.Nk;
+    // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
+    const int valid = count < p.Nk ? count : p.Nk;
+    const int ntiles = (valid + KVT - 1) / KVT;
+    const int32_t *idx = GATHER ? p.indices + ((int64_t)bh * p.G + g) * p.idx_stride : nullptr;
+    const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
+    const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
+    const int row0 = g * QG + w * QW;
+
+    // ---- Q^T fragments (B operand): lane = query column li, k = lg*8..lg*8+7 of each 32-wide d step
+    bf16x8 qf[3][4];
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        const int qrow = row0 + qb * 16 + li;
+        const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qrow * p.qs[2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 z = {};
+            qf[qb][ks] = qrow < p.Nq ? *(const bf16x8 *)(qp + ks * 32 + lg * 8) : z;
+        }
+    }
+
+    float prevl[3] = {0.f, 0.f, 0.f};
+    if constexpr (COLSUM) {
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            const int qrow = row0 + qb * 16 + li;
+            prevl[qb] = qrow < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qrow] : 0.f;
+        }
+        if (tid < 2 * KVT) cs_acc[tid] = 0.f;
+    }
+
+    int keys[4];
+    auto load_keys = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pos = t * KVT + (w * 4 + i) * 4 + lg;
+            int key = 0;
+            if (pos < valid) {
+                key = GATHER ? idx[pos] : pos;
+                key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);  // memory safety for malformed indices
+            }
+            keys[i] = key;
+        }
+    };
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (w * 4 + i) * 4 + lg;  // row inside the tile
+            const uint16_t *ksrc = kbase + (int64_t)keys[i] * p.ks[2] + ((li ^ (r & 15)) << 3);
+            const uint16_t *vsrc = vbase + (int64_t)keys[i] * p.vs[2] + ((li ^ ((r & 7) << 1)) << 3);
+            glds16(ksrc, Kl + buf * TILE_BYTES + (w * 4 + i) * 1024);
+            glds16(vsrc, Vl + buf * TILE_BYTES + (w * 4 + i) * 1024);
+        }
+    };
+
+    f32x4 o[3][8];
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float lsum[3] = {0.f, 0.f, 0.f};
+
+    if (ntiles > 0) {
+        load_keys(0);
+        issue(0);
+        if (ntiles > 1) load_keys(1);
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (COLSUM) {
+            if (t > 0 && tid < KVT) {
+                const int pos = (t - 1) * KVT + tid;
+                float *slot = cs_acc + ((t - 1) & 1) * KVT + tid;
+                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(*slot);
+                *slot = 0.f;
+            }
+        }
+        if (t + 1 < ntiles) {
+            issue(buf ^ 1);
+            if (t + 2 < ntiles) load_keys(t + 2);
+        }
+        const unsigned char *Kb = Kl + buf * TILE_BYTES;
+        const unsigned char *Vb = Vl + buf * TILE_BYTES;
+
+        // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
+        f32x4 s[3][4];
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
+                const bf16x8 a = *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(a, qf[qb][ks], s[qb][kt]);
+            }
+        }
+        if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+                }
+        }
+
+        // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
+        bf16x8 pb[3][2];
+        float cacc[4][4];
+        if constexpr (COLSUM) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m[qb], mx);
+            const float msc = m_new * SCALE_LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
+            m[qb] = m_new;
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
+                    psum += pv[kt][r];
+                }
+            lsum[qb] = lsum[qb] * alpha + psum;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
+            }
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                bf16x8 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pk[r] = (__bf16)pv[2 * kp][r];
+                    pk[4 + r] = (__bf16)pv[2 * kp + 1][r];
+                }
+                pb[qb][kp] = pk;
+            }
+            if constexpr (COLSUM) {
+                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
+                const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
+            }
+        }
+        if constexpr (COLSUM) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tot = row16_sum(cacc[kt][r]);
+                    if (li == 0) atomicAdd(cs_acc + buf * KVT + kt * 16 + lg * 4 + r, tot);
+                }
+        }
+
+        // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int row_a = kp * 32 + lg * 4 + (li >> 2);
+                const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
+                const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
+                const s16x4 lo = lds_read_tr16_b64(va);
+                const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
+                const bf16x8 a = __builtin_bit_cast(
+                    bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(a, pb[qb][kp], o[qb][db]);
+            }
+        }
+    }
+
+    if constexpr (COLSUM) {
+        __syncthreads();
+        if (ntiles > 0 && tid < KVT) {
+            const int pos = (ntiles - 1) * KVT + tid;
+            if (pos < p.Nk)
+                p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(cs_acc[((ntiles - 1) & 1) * KVT + tid]);
+        }
+    }
+
+    // ---- epilogue: O = O^T / l ; lane holds 4 consecutive d of one query row per (qb, db)
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        float l = lsum[qb];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
+        const int qrow = row0 + qb * 16 + li;
+        if (qrow >= p.Nq) continue;
+        uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + lg * 4;
+        if (INPLACE && ntiles == 0) continue;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            float x0 = o[qb][db][0] * inv, x1 = o[qb][db][1] * inv, x2 = o[qb][db][2] * inv, x3 = o[qb][db][3] * inv;
+            u32x2 out;
+            if constexpr (INPLACE) {
+                // bf16 store of o_scale*result, then bf16 reduce-add into o (csp_attn.cu:294-300)
+                const u32x2 old = *(const u32x2 *)(op + db * 16);
+                const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
+                const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
+                out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
+                out[1] = pack_bf16x2(__uint_as_float(old[1] << 16) + a2, __uint_as_float(old[1] & 0xffff0000u) + a3);
+            } else {
+                out[0] = pack_bf16x2(x0, x1);
+                out[1] = pack_bf16x2(x2, x3);
+            }
+            *(u32x2 *)(op + db * 16) = out;
+        }
+        if constexpr (WRITE_L) {
+            // l = 1 / (exp2(m*c) * norm) = 1 / sum_j exp(s_ij / sqrt(D))   (dense_attn.cu:225-227)
+            if (lg == 0) p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+        }
+    }
+}
+
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM>
+int launch_attn(const AttnParams &p, hipStream_t stream) {
+    auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, COLSUM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
+        attr_set = true;
+    }
+    const int64_t nblocks = (int64_t)p.B * p.H * p.G;
+    if (nblocks == 0) return CHIPMUNK_OK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), ATTN_LDS_BYTES, stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+int check_common(const void *q, const void *k, const void *v, const void *o, int B, int H, int Nq, int Nk) {
+    CM_CHECK(q && k && v && o, "attention: null tensor pointer");
+    CM_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: B,H,Nq,Nk must be positive (got %d,%d,%d,%d)", B, H, Nq, Nk);
+    CM_CHECK((int64_t)B * H * ((Nq + QG - 1) / QG) < (1ll << 31), "attention: too many query groups");
+    CM_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0,
+             "attention: q/k/v must be 16-byte aligned and o 8-byte aligned");
+    return CHIPMUNK_OK;
+}
+int check_strides(const int64_t *s, const char *name) {
+    CM_CHECK(s != nullptr, "attention: %s strides missing", name);
+    CM_CHECK(s[2] >= HD && s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0,
+             "attention: %s strides must be multiples of 8 elements with a contiguous head dim of 128", name);
+    return CHIPMUNK_OK;
+}
+void contiguous_strides(int64_t *s, int H, int N) {
+    s[0] = (int64_t)H * N * HD;
+    s[1] = (int64_t)N * HD;
+    s[2] = HD;
+}
+
+}  // namespace
+
+extern "C" int chipmunk_csp_attn(const void *q, const void *k, const void *v, void *o, const int64_t q_strides[3],
+                                 const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+                                 const int32_t *indices, const int32_t *counts, int B, int H, int Nq, int Nk,
+                                 int idx_stride, int o_scale, void *stream) {
+    if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
+    CM_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");  // csp_attn.cu:327
+    CM_CHECK(indices && counts, "csp_attn: indices / counts missing");
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    if (int e = check_strides(o_strides, "o")) return e;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i], p.os[i] = o_strides[i];
+    p.indices = indices, p.counts = counts;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
+    p.o_scale = (float)o_scale;
+    return launch_attn<true, true, false, false>(p, (hipStream_t)stream);
+}
+
+extern "C" int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,
+                                     const int32_t *counts, int B, int H, int Nq, int Nk, int idx_stride,
+                                     void *stream) {
+    if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
+    CM_CHECK(indices && counts, "csp_128_attn: indices / counts missing");
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    contiguous_strides(p.qs, H, Nq), contiguous_strides(p.os, H, Nq);
+    contiguous_strides(p.ks, H, Nk), contiguous_strides(p.vs, H, Nk);
+    p.indices = indices, p.counts = counts;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
+    p.o_scale = 1.f;
+    return launch_attn<true, false, false, false>(p, (hipStream_t)stream);
+}
+
+extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                   const int64_t k_strides[3], const int64_t v_strides[3], void *o, float *l, int B,
+                                   int H, int Nq, int Nk, void *stream) {
+    if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
+    CM_CHECK(l != nullptr, "dense_attn: l output missing");
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
+    contiguous_strides(p.os, H, Nq);
+    p.l_out = l;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
+    p.o_scale = 1.f;
+    return launch_attn<false, false, true, false>(p, (hipStream_t)stream);
+}
+
+extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                          const int64_t k_strides[3], const int64_t v_strides[3], const float *pin,
+                                          void *o, void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride,
+                                          void *stream) {
+    if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
+    CM_CHECK(l && cs && pin, "dense_colsum_attn: p / cs / l missing");
+    CM_CHECK(cs_stride >= Nk, "dense_colsum_attn: cs row stride %d < Nk %d", cs_stride, Nk);
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
+    contiguous_strides(p.os, H, Nq);
+    p.l_out = l, p.p_in = pin, p.cs = (uint16_t *)cs, p.cs_stride = cs_stride;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
+    p.o_scale = 1.f;
+    return launch_attn<false, false, true, true>(p, (hipStream_t)stream);
+}

@@ -1,0 +1,89 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/chipmunk_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16 (lane-linear);
+// the global source address is per lane, which is what makes it a gather engine.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even float -> bf16 bits (matches torch / the oracle's f2bf for finite values)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+// pack two floats to a dword of two bf16 (lo in bits 0-15)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// hardware transpose read: each 16-lane group reads a 4x16 b16 block (lane i supplies the address of
+// 4 contiguous elements: block row i/4, columns (i%4)*4..+3) and lane i receives column i (4 rows).
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const void *lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lds_addr));
+}
+
+// 16-lane-row rotate (DPP row_ror:n) -- cross-lane without LDS traffic.
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the total
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_row_ror<8>(x);
+    x += dpp_row_ror<4>(x);
+    x += dpp_row_ror<2>(x);
+    x += dpp_row_ror<1>(x);
+    return x;
+}
+
+// XCD-aware remap of a 1-D grid (8 XCDs, block b is dispatched to XCD b % 8): returns an id such that every
+// XCD works on a contiguous chunk of the logical index space (L2 affinity only, never correctness).  Bijective.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int NX = 8;
+    int xcd = bid % NX, slot = bid / NX;
+    int q = nblocks / NX, r = nblocks % NX;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// ---- host-side error plumbing (thread-local message, see chipmunk_last_error) ----
+void chipmunk_set_error(const char *fmt, ...);
+#define CM_CHECK(cond, ...)                    \
+    do {                                       \
+        if (!(cond)) {                         \
+            chipmunk_set_error(__VA_ARGS__);   \
+            return CHIPMUNK_ERR_INVALID;       \
+        }                                      \
+    } while (0)
+#define CM_LAUNCH_CHECK()                                                          \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            chipmunk_set_error("HIP launch failed: %s", hipGetErrorString(e__));   \
+            return CHIPMUNK_ERR_LAUNCH;                                            \
+        }                                                                          \
+    } while (0)

@@ -1,0 +1,406 @@
+// Indexed IO for gfx950: mask -> indices, top-k indices, indexed copy, bit packing.
+// Replaces reference csrc/indexed_io/{mask_to_indices,topk_indices,copy_indices}.cu and ops/bitpack.py.
+// HBM-bound integer/byte kernels: wide coalesced loads, wave64 ballots / popcounts instead of CUB scans,
+// LDS for the per-row bit matrices.  Results are bit-exact against the reference's ordering rules.
+#include "common.h"
+
+namespace {
+
+// =====================================================================================  mask_to_indices
+// Reference order (mask_to_indices.cu:49-86, one 32-lane warp per row): for residue class t = 0..31 all True columns
+// c == t (mod 32) ascending, then padding with the first False columns ascending.
+//
+// Here one 256-thread workgroup per row:
+//   A. each lane turns 32 mask bytes (one "i-row": columns 32i..32i+31) into a 32-bit word (bits[i] in LDS);
+//   B. 32 wave64 ballots per 64 i-rows transpose the bit matrix: T[t][blk] = 64-bit vector of class t;
+//   C. popcounts + a per-class scan over blocks + a scan over classes give every (class, block) cell its output offset;
+//   D. each lane walks the set bits of its cell and writes the column numbers;
+//   E. one lane appends the padding columns from the untransposed words.
+struct M2IParams {
+    const uint8_t *mask;  // bool bytes [rows, n]  (PACKED == false)  or packed bits [rows*n/8] (PACKED == true)
+    int32_t *indices;
+    int32_t *counts;
+    int n, pad_n, multiple_of;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void mask_to_indices_kernel(const M2IParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = p.n;
+    const int NI = (n + 31) >> 5;   // 32-column words per row
+    const int NB = (NI + 63) >> 6;  // 64-word blocks per row
+    uint32_t *bits = (uint32_t *)smem;                               // [NB*64]
+    unsigned long long *T = (unsigned long long *)(bits + NB * 64);  // [32][NB]
+    uint32_t *pre = (uint32_t *)(T + 32 * NB);                       // [32][NB] exclusive offsets
+    uint32_t *cls = pre + 32 * NB;                                   // [33] class totals / offsets
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t row = blockIdx.x;
+    int32_t *out = p.indices + row * p.pad_n;
+
+    // ---- A: bit words
+    if constexpr (PACKED) {
+        const uint8_t *src = p.mask + ((row * n) >> 3);  // n % 8 == 0 guaranteed by the host
+        const bool aligned4 = ((((uintptr_t)src) & 3) == 0);
+        for (int i = tid; i < NB * 64; i += 256) {
+            uint32_t word = 0;
+            if (i < NI) {
+                const int nbytes = min(4, (n - i * 32 + 7) >> 3);
+                if (aligned4 && nbytes == 4) {
+                    word = *(const uint32_t *)(src + i * 4);
+                } else {
+                    for (int j = 0; j < nbytes; ++j) word |= (uint32_t)src[i * 4 + j] << (8 * j);
+                }
+                const int rem = n - i * 32;
+                if (rem < 32) word &= (1u << rem) - 1u;
+            }
+            bits[i] = word;
+        }
+    } else {
+        const uint8_t *src = p.mask + row * n;
+        const bool aligned16 = ((((uintptr_t)src) & 15) == 0);
+        for (int i = tid; i < NB * 64; i += 256) {
+            uint32_t word = 0;
+            if (i < NI) {
+                if (aligned16 && i * 32 + 32 <= n) {
+                    const u32x4 lo = *(const u32x4 *)(src + i * 32);
+                    const u32x4 hi = *(const u32x4 *)(src + i * 32 + 16);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        // bool bytes are 0/1 (any non-zero counts as true): gather bit 0 of the 4 bytes of each dword
+                        uint32_t x = lo[d], y = hi[d];
+                        x = (x | (x >> 1) | (x >> 2) | (x >> 3) | (x >> 4) | (x >> 5) | (x >> 6) | (x >> 7)) & 0x01010101u;
+                        y = (y | (y >> 1) | (y >> 2) | (y >> 3) | (y >> 4) | (y >> 5) | (y >> 6) | (y >> 7)) & 0x01010101u;
+                        const uint32_t nx = (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
+                        const uint32_t ny = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xfu;
+                        word |= nx << (4 * d);
+                        word |= ny << (16 + 4 * d);
+                    }
+                } else {
+                    const int rem = min(32, n - i * 32);
+                    for (int j = 0; j < rem; ++j) word |= (uint32_t)(src[i * 32 + j] != 0) << j;
+                }
+            }
+            bits[i] = word;
+        }
+    }
+    __syncthreads();
+
+    // ---- B: transpose by ballots (each wave takes blocks w, w+4, ...)
+    for (int blk = w; blk < NB; blk += 4) {
+        const uint32_t word = bits[blk * 64 + lane];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const unsigned long long bal = __ballot((word >> t) & 1u);
+            if (lane == t) mine = bal;
+        }
+        if (lane < 32) T[lane * NB + blk] = mine;
+    }
+    __syncthreads();
+
+    // ---- C: offsets.  One lane per class scans its blocks; then 32 classes are scanned by lane 0.
+    if (tid < 32) {
+        uint32_t run = 0;
+        for (int blk = 0; blk < NB; ++blk) {
+            pre[tid * NB + blk] = run;
+            run += __popcll(T[tid * NB + blk]);
+        }
+        cls[tid + 1] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 32; ++t) {
+            const uint32_t c = cls[t + 1];
+            cls[t] = run;  // exclusive class offset (cls[t+1] is consumed before it is overwritten next iteration)
+            run += c;
+            if (t == 31) cls[32] = run;
+        }
+    }
+    __syncthreads();
+    const int total = (int)cls[32];
+
+    // ---- D: emit.  Consecutive lanes take consecutive blocks of one class => neighbouring output runs.
+    for (int cell = tid; cell < 32 * NB; cell += 256) {
+        const int t = cell / NB, blk = cell - t * NB;
+        unsigned long long v = T[cell];
+        int pos = (int)(cls[t] + pre[cell]);
+        while (v) {
+            const int bit = __builtin_ctzll(v);
+            v &= v - 1;
+            out[pos++] = ((blk * 64 + bit) << 5) + t;
+        }
+    }
+
+    // ---- E: padding with the first False columns (lane 0 only, <= multiple_of-1 columns)
+    if (tid == 0) {
+        const int padded = ((total + p.multiple_of - 1) / p.multiple_of) * p.multiple_of;
+        int pos = total;
+        for (int i = 0; i < NI && pos < padded; ++i) {
+            uint32_t z = ~bits[i];
+            const int rem = n - i * 32;
+            if (rem < 32) z &= (1u << rem) - 1u;
+            while (z && pos < padded) {
+                const int bit = __builtin_ctz(z);
+                z &= z - 1;
+                out[pos++] = i * 32 + bit;
+            }
+        }
+        p.counts[row] = padded;
+    }
+}
+
+// =====================================================================================  topk_indices
+struct TopkParams {
+    const void *act;
+    int32_t *indices;
+    int32_t *counts;
+    int rows, cols, multiple_of;
+    float quantile, random_amount;
+};
+
+template <typename T>
+__device__ __forceinline__ float load_as_float(const T *p, int i);
+template <>
+__device__ __forceinline__ float load_as_float<uint16_t>(const uint16_t *p, int i) { return bf16_bits_to_f32(p[i]); }
+template <>
+__device__ __forceinline__ float load_as_float<_Float16>(const _Float16 *p, int i) { return (float)p[i]; }
+template <>
+__device__ __forceinline__ float load_as_float<float>(const float *p, int i) { return p[i]; }
+
+// counter-based uniform in [0,1): replaces cuRAND Philox of topk_indices.cu:46-49,108 (RNG streams cannot match)
+__device__ __forceinline__ float hash_uniform(uint32_t row, uint32_t col) {
+    uint32_t x = row * 0x9E3779B9u ^ (col + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// block-wide ordered compaction step: returns this thread's output slot (or -1) and advances *base
+__device__ __forceinline__ int compact_slot(bool keep, int lane, int w, uint32_t *wave_tot, int &base) {
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[w] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int i = 0; i < w; ++i) off += wave_tot[i];
+    const int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    base += tot;
+    return keep ? off + before : -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void topk_indices_kernel(const TopkParams p) {
+    __shared__ float sample[1024];
+    __shared__ int last_invalid[1024];
+    __shared__ uint32_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = blockIdx.x;
+    const T *x = (const T *)p.act + (int64_t)row * p.cols;
+    int32_t *out = p.indices + (int64_t)row * p.cols;
+    const int cols = p.cols;
+
+    if (p.quantile == 0.f) {  // keep everything (topk_indices.cu:51-59)
+        for (int c = tid; c < cols; c += 256) out[c] = c;
+        if (tid == 0) p.counts[row] = cols;
+        return;
+    }
+    if (p.quantile == 1.f) {  // keep nothing (topk_indices.cu:60-69)
+        for (int c = tid; c < cols; c += 256) out[c] = -1;
+        if (tid == 0) p.counts[row] = 0;
+        return;
+    }
+    // ---- threshold = element int(1024*q) of the ascending-sorted first 1024 values (topk_indices.cu:91-101)
+    for (int i = tid; i < 1024; i += 256) sample[i] = load_as_float<T>(x, i);
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < 1024; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a = sample[i], b = sample[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        sample[i] = b;
+                        sample[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const float thr = sample[(int)(1024 * p.quantile)];
+    for (int i = tid; i < 1024; i += 256) last_invalid[i] = -1;
+    __syncthreads();
+
+    // ---- ordered compaction of kept columns; remember the last rejected column of every residue class mod 1024
+    int base = 0;
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int c = c0 + tid;
+        bool keep = false;
+        if (c < cols) {
+            keep = load_as_float<T>(x, c) >= thr;
+            if (!keep && p.random_amount > 0.f) keep = hash_uniform(row, c) < p.random_amount;
+            if (!keep) last_invalid[c & 1023] = c;  // ascending c per slot => ends as the last rejected column
+        }
+        const int slot = compact_slot(keep, lane, w, wave_tot, base);
+        if (slot >= 0) out[slot] = c;
+    }
+    const int kept = base;
+    const int mod = kept % p.multiple_of;
+    int pad = mod == 0 ? 0 : p.multiple_of - mod;
+    if (tid == 0) p.counts[row] = kept + pad;
+    __syncthreads();
+    // ---- padding candidates in ascending residue order (a deterministic choice among the reference's outcomes)
+    for (int t0 = 0; t0 < 1024 && pad > 0; t0 += 256) {
+        const int cand = last_invalid[t0 + tid];
+        int pbase = 0;
+        const int slot = compact_slot(cand != -1, lane, w, wave_tot, pbase);
+        if (slot >= 0 && slot < pad) out[base + slot] = cand;
+        const int used = pbase < pad ? pbase : pad;
+        base += used;
+        pad -= used;
+    }
+}
+
+// =====================================================================================  copy_indices
+template <typename T>
+__global__ __launch_bounds__(256) void copy_indices_kernel(const T *src, T *dst, const int32_t *inds,
+                                                           const int32_t *counts, int M, int R, int F) {
+    const int64_t grow = blockIdx.x;                 // row over B*M*R
+    const int64_t b = grow / ((int64_t)M * R);
+    const int base_m = (int)((grow % ((int64_t)M * R)) / R);
+    const int cnt = counts[b * M + base_m];
+    const int32_t *ii = inds + (b * M + base_m) * (int64_t)F;
+    for (int c = threadIdx.x; c < cnt; c += 256) {
+        const int col = ii[c];
+        dst[grow * F + col] = src[grow * F + col];
+    }
+}
+
+// =====================================================================================  bitpack / bitunpack
+__global__ __launch_bounds__(256) void bitpack_kernel(const uint8_t *mask, uint8_t *packed, int64_t n) {
+    const int64_t nb = (n + 7) >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
+        uint8_t byte = 0;
+        if (i * 8 + 8 <= n && ((((uintptr_t)mask) & 7) == 0)) {
+            unsigned long long v = *(const unsigned long long *)(mask + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) byte |= (uint8_t)((((v >> (8 * j)) & 0xffull) != 0) << j);
+        } else {
+            for (int j = 0; j < 8 && i * 8 + j < n; ++j) byte |= (uint8_t)((mask[i * 8 + j] != 0) << j);
+        }
+        packed[i] = byte;
+    }
+}
+__global__ __launch_bounds__(256) void bitunpack_kernel(const uint8_t *packed, uint8_t *mask, int64_t n) {
+    const int64_t nb = (n + 7) >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
+        const uint8_t byte = packed[i];
+        if (i * 8 + 8 <= n && ((((uintptr_t)mask) & 7) == 0)) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v |= (unsigned long long)((byte >> j) & 1u) << (8 * j);
+            *(unsigned long long *)(mask + i * 8) = v;
+        } else {
+            for (int j = 0; j < 8 && i * 8 + j < n; ++j) mask[i * 8 + j] = (byte >> j) & 1u;
+        }
+    }
+}
+
+size_t m2i_lds_bytes(int n) {
+    const int NI = (n + 31) >> 5, NB = (NI + 63) >> 6;
+    return (size_t)NB * 64 * 4 + (size_t)32 * NB * 8 + (size_t)32 * NB * 4 + 33 * 4 + 16;
+}
+
+template <bool PACKED>
+int launch_m2i(const void *mask, int32_t *indices, int32_t *counts, int64_t rows, int n, int pad_n, int multiple_of,
+               void *stream) {
+    CM_CHECK(mask && indices && counts, "mask_to_indices: null pointer");
+    CM_CHECK(rows >= 0 && n > 0 && pad_n >= n && multiple_of > 0, "mask_to_indices: bad sizes rows=%lld n=%d pad_n=%d multiple_of=%d",
+             (long long)rows, n, pad_n, multiple_of);
+    CM_CHECK(rows < (1ll << 31), "mask_to_indices: too many rows");
+    if (PACKED) CM_CHECK(n % 8 == 0, "packed_mask_to_indices: n must be a multiple of 8 (got %d)", n);
+    const size_t lds = m2i_lds_bytes(n);
+    CM_CHECK(lds <= 160 * 1024, "mask_to_indices: row length %d needs %zu B of LDS (> 160 KiB)", n, lds);
+    if (rows == 0) return CHIPMUNK_OK;
+    auto kern = mask_to_indices_kernel<PACKED>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    M2IParams p = {(const uint8_t *)mask, indices, counts, n, pad_n, multiple_of};
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+}  // namespace
+
+extern "C" int chipmunk_mask_to_indices(const void *mask, int32_t *indices, int32_t *counts, int64_t rows, int n,
+                                        int pad_n, int multiple_of, void *stream) {
+    return launch_m2i<false>(mask, indices, counts, rows, n, pad_n, multiple_of, stream);
+}
+
+extern "C" int chipmunk_packed_mask_to_indices(const void *packed, int32_t *indices, int32_t *counts, int64_t rows,
+                                               int n, int pad_n, int multiple_of, void *stream) {
+    return launch_m2i<true>(packed, indices, counts, rows, n, pad_n, multiple_of, stream);
+}
+
+extern "C" int chipmunk_topk_indices(const void *activation, int dtype, int32_t *indices, int32_t *counts, int rows,
+                                     int cols, double sparsity_amount, int multiple_of, double random_amount,
+                                     void *stream) {
+    CM_CHECK(activation && indices && counts, "topk_indices: null pointer");
+    CM_CHECK(rows >= 0 && cols >= 1024, "topk_indices: rows >= 0 and cols >= 1024 required (the quantile is taken over the first 1024 columns); got rows=%d cols=%d", rows, cols);
+    CM_CHECK(multiple_of > 0, "topk_indices: multiple_of must be positive");
+    CM_CHECK(sparsity_amount >= 0.0 && sparsity_amount <= 1.0, "topk_indices: sparsity_amount must be in [0,1]");
+    if (rows == 0) return CHIPMUNK_OK;
+    TopkParams p = {activation, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount};
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case CHIPMUNK_DTYPE_BF16: hipLaunchKernelGGL(topk_indices_kernel<uint16_t>, dim3(rows), dim3(256), 0, s, p); break;
+        case CHIPMUNK_DTYPE_FP16: hipLaunchKernelGGL(topk_indices_kernel<_Float16>, dim3(rows), dim3(256), 0, s, p); break;
+        case CHIPMUNK_DTYPE_FP32: hipLaunchKernelGGL(topk_indices_kernel<float>, dim3(rows), dim3(256), 0, s, p); break;
+        default: CM_CHECK(false, "topk_indices: unsupported dtype code %d", dtype);
+    }
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const int32_t *counts, int B,
+                                     int M, int R, int F, int elem_size, void *stream) {
+    CM_CHECK(src && dst && inds && counts, "copy_indices: null pointer");
+    CM_CHECK(B >= 0 && M > 0 && R > 0 && F > 0, "copy_indices: bad sizes");
+    CM_CHECK(elem_size == 2 || elem_size == 4, "copy_indices: element size must be 2 or 4 bytes (got %d)", elem_size);
+    const int64_t rows = (int64_t)B * M * R;
+    if (rows == 0) return CHIPMUNK_OK;
+    CM_CHECK(rows < (1ll << 31), "copy_indices: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_size == 2)
+        hipLaunchKernelGGL(copy_indices_kernel<uint16_t>, dim3((unsigned)rows), dim3(256), 0, s, (const uint16_t *)src,
+                           (uint16_t *)dst, inds, counts, M, R, F);
+    else
+        hipLaunchKernelGGL(copy_indices_kernel<uint32_t>, dim3((unsigned)rows), dim3(256), 0, s, (const uint32_t *)src,
+                           (uint32_t *)dst, inds, counts, M, R, F);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream) {
+    CM_CHECK(mask && packed && n >= 0, "bitpack: bad arguments");
+    if (n == 0) return CHIPMUNK_OK;
+    const int64_t nb = (n + 7) >> 3;
+    const unsigned grid = (unsigned)((nb + 255) / 256 < 8192 ? (nb + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bitpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)mask,
+                       (uint8_t *)packed, n);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream) {
+    CM_CHECK(mask && packed && n >= 0, "bitunpack: bad arguments");
+    if (n == 0) return CHIPMUNK_OK;
+    const int64_t nb = (n + 7) >> 3;
+    const unsigned grid = (unsigned)((nb + 255) / 256 < 8192 ? (nb + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bitunpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)packed,
+                       (uint8_t *)mask, n);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}

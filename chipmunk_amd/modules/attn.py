@@ -1,0 +1,169 @@
+"""Sparse-delta attention layer state machine (mirror of reference ``src/chipmunk/modules/attn.py:16-204``).
+
+Per (inference step, layer) one of four things happens (reference ``_fast_attention``, ``:86-190``):
+
+* layer < ``first_n_dense_layers``               -> dense attention;
+* full step, step 0                               -> dense attention, remember ``l`` (softmax denominators);
+* full step, step 1 or ``recompute_mask``         -> dense attention with column sums -> pick the keys every 192-query
+                                                     group keeps (top-k of the column sums [+ 1% random + static local
+                                                     mask]) -> ``o_cache = o_dense - sparse(q, k, v)``;
+* sparse step                                     -> ``o = o_cache + sparse(q, k, v)`` over the kept keys only.
+
+Two index styles, selected by the config exactly as in the reference:
+``should_compress_indices`` (HunyuanVideo/Wan): a bit-packed bool mask is stored and turned into (indices, counts)
+every step; otherwise (FLUX) ``torch.topk`` indices are stored directly and the in-place kernel is used.
+With ``attn.fused_packed_mask_to_indices`` (default on, not in the reference) the bit-packed mask goes straight to the
+indices kernel instead of through a materialised bool mask -- same indices, 8x less traffic.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import ops
+from ..ops.voxel import get_local_indices_with_text
+from ..util.config import GLOBAL_CONFIG
+from ..util.layer_counter import LayerCounter
+from ..util.storage import AttnStorage
+
+# shared by all layers, initialised from the sequence shape (reference attn.py:12-14)
+singleton_static_mask: Optional[Tensor] = None
+singleton_video_query_groups: Optional[Tensor] = None
+
+
+def _cdiv(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+class SparseDiffAttn(nn.Module):
+    def __init__(self, layer_num: int, layer_counter: LayerCounter):
+        super().__init__()
+        self.layer_num = layer_num
+        self.layer_counter = layer_counter
+        self.storage = AttnStorage(layer_num, init_names=["indices", "out_cache"])
+        self.mask_shape = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
+
+    # ------------------------------------------------------------------------------------------ static mask
+    def initialize_static_mask(self, seq_shape: Tuple, txt_len: int, local_heads_num: int, device: torch.device):
+        if len(seq_shape) == 2:
+            raise NotImplementedError("Not yet implemented for 2D sequences")
+        tt, th, tw = seq_shape
+        cfg = GLOBAL_CONFIG["attn"]
+        n_video = tt * th * tw
+        topk = int(cfg["top_keys"] * n_video)
+        lv = cfg["local_voxels"]
+        mask, _, _ = get_local_indices_with_text(vid_shape=(tt, th, tw), txt_len=txt_len, voxel_shape=(4, 6, 8),
+                                                 local_shape=(lv, lv, lv), rk=cfg["random_keys"], device=device)
+        if cfg["local_1d_window"] > 0:
+            window = int(cfg["local_1d_window"] * n_video)
+            for qg in range(n_video // 192):
+                centre = qg * 192 + 96
+                mask[qg, max(0, centre - window // 2):min(n_video, centre + window // 2)] = True
+        mask = mask[None, None, :, :].expand(1, local_heads_num, -1, -1).contiguous()
+        sparse_groups = (mask.sum(dim=-1, keepdim=True) + topk) < (n_video + txt_len)
+        global singleton_static_mask, singleton_video_query_groups
+        singleton_static_mask = mask
+        singleton_video_query_groups = sparse_groups
+
+    def random_and_topk(self, cs: Tensor, topk: int) -> Tensor:
+        """1% random keys + top-k column sums, limited to the groups that are sparse at all, plus the static mask."""
+        mask = torch.randint(0, 100, cs.shape, device=cs.device, dtype=torch.uint8) == 0
+        mask.scatter_(-1, cs.topk(k=topk, dim=-1).indices, True)
+        qg, n = cs.shape[-2], cs.shape[-1]
+        return (mask * singleton_video_query_groups[..., :qg, :n]) | singleton_static_mask[..., :qg, :n]
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _stored_indices(self, multiple_of: int, bm: int):
+        cfg = GLOBAL_CONFIG["attn"]
+        if cfg["should_compress_indices"]:
+            packed = self.storage.get_indices()
+            shape = self.mask_shape[self.layer_counter.cur_model_invocation_per_step]
+            if cfg.get("fused_packed_mask_to_indices", False) and packed.is_cuda and shape[-1] % 8 == 0:
+                return ops.packed_mask_to_indices(packed, shape, multiple_of, bm)
+            return ops.mask_to_indices(ops.bitunpack(packed, shape), multiple_of, bm)
+        return self.storage.get_indices(), self.storage.get_counts()
+
+    # ------------------------------------------------------------------------------------------ state machine
+    def _fast_attention(self, q: Tensor, k: Tensor, v: Tensor, inference_step: int, do_full_step: bool) -> Tensor:
+        cfg = GLOBAL_CONFIG["attn"]
+        bm = cfg["mbm"]
+        assert bm == 192, "The kernel was written for BM=192. You may need to change the kernel."
+        do_padding = cfg["pad_qkv_before_kernel"]
+        multiple_of = 128 if do_padding else cfg["counts_multiple_of"]
+
+        if self.layer_num < cfg["first_n_dense_layers"]:
+            o, _ = ops.dense_attn(q, k, v)
+            return o
+
+        if do_full_step:
+            if inference_step == 0:
+                o, lse = ops.dense_attn(q, k, v) if do_padding else torch.ops.chipmunk.dense_attn(q, k, v)
+                lse[..., k.shape[-2]:, :] = 0
+                self.storage.set_lse_constants(lse)
+                return o
+
+            if inference_step == 1 or cfg["recompute_mask"]:
+                prev_lse = self.storage.get_lse_constants()
+                if do_padding:
+                    o, bs, lse = ops.dense_colsum_attn(q, k, v, prev_lse)
+                else:
+                    o, bs, lse = torch.ops.chipmunk.dense_colsum_attn(q, k, v, prev_lse)
+                lse[..., k.shape[-2]:, :] = 0
+                self.storage.set_lse_constants(lse)
+                tk = int(multiple_of * round((cfg["top_keys"] * k.shape[-2]) / multiple_of))
+                if cfg["should_compress_indices"]:
+                    if tk > 0:
+                        mask = self.random_and_topk(bs, tk)
+                    else:
+                        mask = singleton_static_mask[..., :bs.shape[-2], :bs.shape[-1]]
+                    packed, mask_shape = ops.bitpack(mask)
+                    self.mask_shape[self.layer_counter.cur_model_invocation_per_step] = mask_shape
+                    self.storage.set_indices(packed)
+                    inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
+                else:
+                    kseq = k.shape[-2]
+                    bs = bs[..., :_cdiv(kseq, bm), :kseq]
+                    inds = torch.topk(bs, k=tk, dim=-1).indices
+                    counts = torch.full((q.shape[0], q.shape[1], _cdiv(q.shape[-2], bm)), tk, device=q.device,
+                                        dtype=torch.int32)
+                    pad = torch.empty((*counts.shape, q.shape[-2] - tk), device=q.device, dtype=torch.int32)
+                    inds = torch.cat([inds, pad], dim=-1).to(torch.int32)
+                    self.storage.set_indices(inds)
+                    self.storage.set_counts(counts)
+            else:
+                o, _ = ops.dense_attn(q, k, v)
+
+            if not cfg["recompute_mask"]:
+                inds, counts = self._stored_indices(multiple_of, bm)
+
+            if do_padding:
+                o_cache = o - ops.csp_attn(q, k, v, inds, counts)
+            else:
+                o_cache = o.clone()
+                torch.ops.chipmunk.csp_attn(q, k, v, o_cache, inds, counts, -1)
+            self.storage.set_out_cache(o_cache)
+            return o
+
+        # sparse step
+        inds, counts = self._stored_indices(multiple_of, bm)
+        o = self.storage.get_out_cache()
+        if do_padding:
+            return o + ops.csp_attn(q, k, v, inds, counts)
+        if not self.storage.out_cache.is_offload_enabled:
+            o = o.clone()  # the kernel accumulates in place and the cache must survive (reference attn.py:186-188)
+        torch.ops.chipmunk.csp_attn(q, k, v, o, inds, counts, 1)
+        return o
+
+    def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+        if not GLOBAL_CONFIG["attn"]["is_enabled"]:
+            return F.scaled_dot_product_attention(q, k, v)
+        do_full_step = self.layer_counter.should_do_full_attn_step()
+        out = self._fast_attention(q, k, v, self.layer_counter.cur_inference_step, do_full_step)
+        self.layer_counter.increment()
+        return out
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)

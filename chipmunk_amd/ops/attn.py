@@ -1,0 +1,64 @@
+"""Attention op wrappers (mirror of reference ``src/chipmunk/ops/attn.py:42-169``: same names, arguments, return
+shapes).  The reference pads q (and the index rows) to a multiple of 192 with extra copies because its kernels demand
+it; the gfx950 kernels mask the ragged last group themselves, so no q copy is made here -- only the documented return
+contract is kept: ``l`` comes back padded to a multiple of 192 with zeros past ``n`` ("leave l padded to pass back in",
+reference ``:77``) and ``cs`` is cropped to ``[..., ceil(Nk/192), Nk]`` (reference ``:118-126``).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+PM = 192  # query rows per group
+
+
+def _pad_len(n: int) -> int:
+    return ((n + PM - 1) // PM) * PM
+
+
+def _last_dim_contiguous(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def dense_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense attention; returns ``(o [..., n, d], l [..., pad192(n), 1] fp32)`` with ``l[n:] = 0``."""
+    n = q.shape[-2]
+    o, l = torch.ops.chipmunk.dense_attn(_last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v))
+    padded = _pad_len(n)
+    if padded != n:
+        l = F.pad(l, (0, 0, 0, padded - n))
+    return o, l
+
+
+def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torch.Tensor
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Dense attention + 192-row column sums of the probabilities normalised by last step's ``p``.
+
+    ``p`` is the (padded) ``l`` returned by the previous ``dense_attn`` / ``dense_colsum_attn`` call.
+    Returns ``(o, cs [..., ceil(Nk/192), Nk] bf16, l padded)``.
+    """
+    n = q.shape[-2]
+    padded = _pad_len(n)
+    assert p.shape[-2] in (n, padded), "p must be the l vector of the previous full step"
+    p_rows = p[..., :n, :].contiguous()
+    o, cs, l = torch.ops.chipmunk.dense_colsum_attn(_last_dim_contiguous(q), _last_dim_contiguous(k),
+                                                    _last_dim_contiguous(v), p_rows)
+    if padded != n:
+        l = F.pad(l, (0, 0, 0, padded - n))
+    kseq = k.shape[-2]
+    kgroups = (kseq + PM - 1) // PM
+    if cs.shape[-2] != kgroups or cs.shape[-1] != kseq:
+        cs = cs[..., :kgroups, :kseq]
+    return o, cs, l
+
+
+def csp_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, indices: torch.Tensor,
+             indices_counts: torch.Tensor) -> torch.Tensor:
+    """Out-of-place column-sparse attention (reference ``ops/attn.py:134-169`` -> ``csp_128_attn``)."""
+    return torch.ops.chipmunk.csp_128_attn(q.contiguous(), k.contiguous(), v.contiguous(), indices.contiguous(),
+                                           indices_counts.contiguous())
+
+
+__all__ = ["csp_attn", "dense_attn", "dense_colsum_attn"]

@@ -1,0 +1,82 @@
+"""Sparse-MLP op wrappers (mirror of reference ``src/chipmunk/ops/mlp.py:7-92``).
+
+``run_e2e`` (exported as ``chipmunk_amd.ops.mlp``) = packed GEMM1 with fused bias+GeLU+cache-subtract, then
+scatter-add of the deltas into the column-major activation cache and GEMM2 accumulating into the output cache.
+Both GEMMs are native HIP kernels here; the reference's GEMM2 is a Triton kernel whose CUfunction pointer is passed
+through the op as an int (``ops/mlp.py:42``) -- the argument is kept (value 0) and ignored.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .indexed_io import scatter_add
+
+USE_FUSED_MLP_MATMUL_2 = True
+csp_mlp_mm2_function_ptr = 0  # placeholder for the reference's Triton kernel pointer (triton/csp_mlp_mm2.py:131-138)
+
+
+def mm1(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc1b: torch.Tensor,
+        sparse_act_T: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
+        scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None) -> None:
+    assert x.dtype == torch.bfloat16
+    assert sparse_act_packed.dtype == torch.bfloat16
+    assert sparse_act_T.dtype == torch.bfloat16
+    if fc1w.dtype == torch.bfloat16:
+        torch.ops.chipmunk.csp_mlp_mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
+    elif fc1w.dtype == torch.float8_e4m3fn:
+        # reference routes to triton csp_mlp_mm1_fp8 (ops/mlp.py:22-23), a path that is broken as shipped
+        # (modules/mlp.py:97 dereferences a list) -- scheduled as a later row, see DESIGN.md
+        raise NotImplementedError("fp8 csp_mlp_mm1 is not built yet on gfx950 (reference path is broken as shipped)")
+    else:
+        raise ValueError(f"Unsupported dtype: {fc1w.dtype}")
+
+
+def mm2_fused(packed: torch.Tensor, unpacked_colmajor: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
+              sparse_act_packed: torch.Tensor, fc2wT: torch.Tensor, cached_out: torch.Tensor,
+              num_sms_scatter_add: int) -> None:
+    assert sparse_act_packed.dtype == torch.bfloat16
+    assert fc2wT.dtype == torch.bfloat16
+    assert cached_out.dtype == torch.bfloat16
+    torch.ops.chipmunk.csp_mlp_mm2_and_scatter_add(
+        packed.unsqueeze(0), unpacked_colmajor.unsqueeze(0), indices.unsqueeze(0), counts.unsqueeze(0),
+        sparse_act_packed.unsqueeze(0), fc2wT.unsqueeze(0), cached_out.unsqueeze(0), num_sms_scatter_add,
+        csp_mlp_mm2_function_ptr)
+
+
+def csp_mlp_mm2(sparse_act_packed: torch.Tensor, fc2wT: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
+                cached_out: torch.Tensor, num_sms: int = 0) -> None:
+    """Native counterpart of the reference's Triton ``csp_mlp_mm2`` (triton/csp_mlp_mm2.py:104-129)."""
+    torch.ops.chipmunk.csp_mlp_mm2(sparse_act_packed, fc2wT, indices, counts, cached_out)
+
+
+def mm2_unfused(sparse_act_packed: torch.Tensor, fc2wT: torch.Tensor, cached_out: torch.Tensor,
+                unpacked_colmajor: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
+                num_sms_scatter_add: int) -> None:
+    assert sparse_act_packed.dtype == torch.bfloat16
+    assert fc2wT.dtype == torch.bfloat16
+    assert cached_out.dtype == torch.bfloat16
+    scatter_add(sparse_act_packed, unpacked_colmajor, indices, counts, num_sms_scatter_add)
+    csp_mlp_mm2(sparse_act_packed, fc2wT, indices, counts, cached_out, 132 - num_sms_scatter_add)
+
+
+@torch.compiler.disable
+def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: torch.Tensor, indices: torch.Tensor,
+            counts: torch.Tensor, sparse_act_T: torch.Tensor, cached_out: torch.Tensor, num_sms_scatter_add: int,
+            mm1_scale_a: Optional[torch.Tensor] = None, mm1_scale_b: Optional[torch.Tensor] = None) -> None:
+    M, K1 = x.shape
+    K2, K1_ = fc1w.shape
+    assert K1 == K1_, "K1 must match"
+    K2_, _N = fc2w_T.shape
+    assert K2 == K2_, "K2 must match"
+    sparse_act_packed = torch.empty((M, K2), device=x.device, dtype=x.dtype)
+    mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts, mm1_scale_a, mm1_scale_b)
+    if USE_FUSED_MLP_MATMUL_2:
+        mm2_fused(sparse_act_packed, sparse_act_T, indices, counts, sparse_act_packed, fc2w_T, cached_out,
+                  num_sms_scatter_add)
+    else:
+        mm2_unfused(sparse_act_packed, fc2w_T, cached_out, sparse_act_T, indices, counts, num_sms_scatter_add)
+
+
+__all__ = ["mm1", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2"]

@@ -1,0 +1,5 @@
+from .config import GLOBAL_CONFIG
+from .layer_counter import LayerCounter
+from .storage import AttnStorage, MlpStorage, MaybeOffloadedTensor
+
+__all__ = ["GLOBAL_CONFIG", "LayerCounter", "AttnStorage", "MlpStorage", "MaybeOffloadedTensor"]

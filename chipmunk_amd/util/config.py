@@ -1,0 +1,114 @@
+"""Global configuration of the sparse path (mirror of reference ``src/chipmunk/util/config.py:4-107``).
+
+Key names, nesting and defaults are the reference's (model code and the shipped ``chipmunk-config.yml`` files address
+them by name); ``load_from_file`` deep-merges a YAML file into ``GLOBAL_CONFIG`` in place so every module that imported
+the dict sees the update.  Additions of this build are listed under ``AMD_EXTRA_KEYS``.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict
+
+import yaml
+
+BASE_CONFIG: Dict[str, Any] = {
+    "num_model_invocations_per_inference_step": 1,
+    "should_profile": False,
+    "generation_index": 0,
+    "steps": 50,
+    "world_size": 1,
+    "mlp": {
+        "is_enabled": True,
+        "is_fp8": False,
+        "top_keys": "dd",  # deliberately not a float: a config file must set it (reference config.py:16)
+        "random_keys": 0.05,
+        "full_step_every": 10,
+        "block_mask_cache": 2,
+        "first_n_dense_layers": 2,
+        "counts_multiple_of": 256,
+        "bm": 128,
+        "mbm": 128,
+    },
+    "patchify": {
+        "is_enabled": True,
+        "chunk_size_1": 8,
+        "chunk_size_2": 4,
+    },
+    "attn": {
+        "is_enabled": True,
+        "top_keys": 0.05,
+        "random_keys": 0.01,
+        "local_voxels": 0,
+        "local_1d_window": 0,
+        "first_n_dense_layers": 2,
+        "full_step_every": 10,
+        "full_step_schedule": None,
+        "recompute_mask": True,
+        "should_compress_indices": True,
+        "counts_multiple_of": 128,
+        "pad_qkv_before_kernel": True,
+        "mbm": 192,
+    },
+    "offloading": {
+        "global_disable_offloading": False,
+        "mlp.out_cache": False,
+        "mlp.indices": False,
+        "mlp.counts": False,
+        "mlp.sparse_act_T": False,
+        "mlp.blockmean_mid_cache": False,
+        "attn.out_cache": True,
+        "attn.indices": True,
+        "attn.counts": False,
+        "attn.lse_constants": False,
+        "text_encoders": True,
+    },
+    "step_caching": {
+        "is_enabled": True,
+        "skip_step_schedule": {7, 11, 13, 14, 15, 17, 18, 19, 21, 22, 23, 25, 26, 27, 29, 31, 33, 34, 35, 37, 38, 39,
+                               41, 42, 43},
+    },
+}
+
+# Keys that do not exist in the reference.  They default to the reference's behaviour.
+AMD_EXTRA_KEYS: Dict[str, Any] = {
+    # 288 GB of HBM3E holds the whole per-layer cache of HunyuanVideo (60 x 0.95 GB): when set, tensors whose offload
+    # flag is on stay resident on the device as long as `hbm_budget_gb` is not exceeded.
+    "offloading.keep_resident_if_fits": False,
+    "offloading.hbm_budget_gb": 200.0,
+    # use the fused packed-bits -> indices kernel instead of bitunpack + mask_to_indices
+    "attn.fused_packed_mask_to_indices": True,
+}
+BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
+BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
+BASE_CONFIG["attn"]["fused_packed_mask_to_indices"] = AMD_EXTRA_KEYS["attn.fused_packed_mask_to_indices"]
+
+GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
+
+
+def update_global_config(config: Dict[str, Any]) -> None:
+    """Shallow top-level update (reference config.py:81-86)."""
+    GLOBAL_CONFIG.update(config)
+
+
+def _deep_update(dst: Dict[str, Any], src: Dict[str, Any]) -> None:
+    """Recursive in-place merge: nested dicts merge, everything else overwrites (reference config.py:92-98)."""
+    for key, value in src.items():
+        if isinstance(value, dict) and isinstance(dst.get(key), dict):
+            _deep_update(dst[key], value)
+        else:
+            dst[key] = value
+
+
+def load_from_file(config_file: str) -> None:
+    with open(config_file, "r") as f:
+        loaded = yaml.safe_load(f)
+    if loaded:
+        _deep_update(GLOBAL_CONFIG, loaded)
+        print(f"CHIPMUNK: using config file {config_file}")
+
+
+def reset_to_base() -> None:
+    """Restore the defaults in place (test helper; the reference has no equivalent)."""
+    fresh = copy.deepcopy(BASE_CONFIG)
+    GLOBAL_CONFIG.clear()
+    GLOBAL_CONFIG.update(fresh)

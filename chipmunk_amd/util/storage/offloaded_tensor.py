@@ -1,0 +1,159 @@
+"""Per-layer cache tensors with optional pinned-host offload (mirror of reference
+``src/chipmunk/util/storage/offloaded_tensor.py:20-178``; same public surface).
+
+MI355X-first differences from the reference, none of which change results:
+
+* the pinned host buffer (``hipHostMalloc`` through torch's pinned allocator) is sized to the tensor actually stored
+  instead of a fixed 1.23 GB / 410 MB per layer per name (reference ``:42-44,71``), and is reused across steps;
+* copies are ``hipMemcpyAsync`` (``copy_(non_blocking=True)``) on two process-wide side streams created lazily on first
+  use -- importing the package never touches the device (the reference creates CUDA streams at import, ``:12-13``);
+* residency policy: with ``offloading.keep_resident_if_fits`` a tensor whose offload flag is set stays in HBM while the
+  running total is under ``offloading.hbm_budget_gb`` (288 GB holds HunyuanVideo's 57 GB of per-layer caches);
+* ``load_async`` records the consumer on the LOAD stream (the reference records the offload stream, ``:160``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from ..config import GLOBAL_CONFIG
+
+# how many layers' worth of device slots exist per tensor name (reference :5)
+PIPELINE_DEPTH = 2
+assert PIPELINE_DEPTH > 1, "a pipeline depth of 1 would serialise every layer behind its own host copy"
+
+_streams: Dict[str, "torch.cuda.Stream"] = {}
+# device slots shared by all layers: gpu_tensors[name][layer % PIPELINE_DEPTH]
+gpu_tensors: Dict[str, List[Optional[torch.Tensor]]] = {}
+_resident_bytes = 0
+
+
+def _side_stream(kind: str) -> "torch.cuda.Stream":
+    if kind not in _streams:
+        _streams[kind] = torch.cuda.Stream()
+    return _streams[kind]
+
+
+def offload_stream() -> "torch.cuda.Stream":
+    return _side_stream("offload")
+
+
+def load_stream() -> "torch.cuda.Stream":
+    return _side_stream("load")
+
+
+class MaybeOffloadedTensor:
+    # kept for source compatibility with code that passes cpu_buf_size=MaybeOffloadedTensor.LARGE_BUF_SIZE;
+    # the value is only a hint here (buffers are sized to the real tensor).
+    LARGE_BUF_SIZE = 1 * 32 * 150000 * 128 * 2
+    MEDIUM_BUF_SIZE = 1 * 32 * 50000 * 128 * 2
+    SMALL_BUF_SIZE = 1 * 32 * 15000 * 128 * 2
+
+    @torch.compiler.disable
+    def __init__(self, name: str, layer_num: int, dtype: torch.dtype, device: torch.device,
+                 cpu_buf_size: int = LARGE_BUF_SIZE):
+        flags = GLOBAL_CONFIG["offloading"]
+        if name not in flags:
+            raise ValueError(f"Invalid tensor name: {name}. Expected one of: {flags.keys()}")
+        self.name = name
+        self.layer_num = layer_num
+        self.layer_key = layer_num % PIPELINE_DEPTH
+        self.dtype = dtype
+        self.device = device
+        self.is_offload_enabled = bool(not flags["global_disable_offloading"] and flags[name])
+        n_inv = GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
+        self.cpu_buf: List[Optional[torch.Tensor]] = [None] * n_inv   # pinned, allocated on first offload
+        self.gpu_tensor: List[Optional[torch.Tensor]] = [None] * n_inv  # resident path
+        self.real_shape: List[Optional[torch.Size]] = [None] * n_inv
+        self._resident: List[bool] = [False] * n_inv
+        self.load_completed_event = None
+        self.model_invocation_count = 0
+        if name not in gpu_tensors:
+            gpu_tensors[name] = [None] * PIPELINE_DEPTH
+
+    # -- bookkeeping -------------------------------------------------------------------------------------------
+    def complete_cur_layer(self) -> None:
+        self.model_invocation_count += 1
+
+    def get_cur_model_invocation_key(self) -> int:
+        return self.model_invocation_count % GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
+
+    def _stays_resident(self, key: int, nbytes: int) -> bool:
+        global _resident_bytes
+        if not self.is_offload_enabled:
+            return True
+        if self._resident[key]:
+            return True
+        flags = GLOBAL_CONFIG["offloading"]
+        if flags.get("keep_resident_if_fits", False):
+            if _resident_bytes + nbytes <= float(flags.get("hbm_budget_gb", 0.0)) * (1 << 30):
+                _resident_bytes += nbytes
+                self._resident[key] = True
+                return True
+        return False
+
+    # -- device -> host ----------------------------------------------------------------------------------------
+    @torch.compiler.disable
+    def offload(self, gpu_tensor: torch.Tensor) -> None:
+        key = self.get_cur_model_invocation_key()
+        self.real_shape[key] = gpu_tensor.shape
+        if self._stays_resident(key, gpu_tensor.numel() * gpu_tensor.element_size()):
+            self.gpu_tensor[key] = gpu_tensor
+            return
+        buf = self.cpu_buf[key]
+        if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype:
+            buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
+            self.cpu_buf[key] = buf
+        side = offload_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf[: gpu_tensor.numel()].view(gpu_tensor.shape).copy_(gpu_tensor, non_blocking=True)
+            gpu_tensor.record_stream(side)
+
+    def offload_cur_value(self) -> None:
+        self.offload(self.get_loaded_value())
+
+    # -- host -> device ----------------------------------------------------------------------------------------
+    def _is_resident_now(self) -> bool:
+        return (not self.is_offload_enabled) or self._resident[self.get_cur_model_invocation_key()]
+
+    def get_loaded_value(self) -> Optional[torch.Tensor]:
+        if self._is_resident_now():
+            return self.gpu_tensor[self.get_cur_model_invocation_key()]
+        slot = gpu_tensors[self.name][self.layer_key]
+        assert slot is not None, (
+            f"Tensor {self.name} is not loaded yet for layer {self.layer_num}. "
+            "Please call load_async() first (followed by load_async_wait())")
+        return slot
+
+    @torch.compiler.disable
+    def load_async(self) -> Optional[torch.Tensor]:
+        key = self.get_cur_model_invocation_key()
+        shape = self.real_shape[key]
+        if shape is None:  # nothing stored yet
+            return None
+        if self._is_resident_now():
+            return self.gpu_tensor[key]
+        slot = gpu_tensors[self.name][self.layer_key]
+        if slot is None or slot.shape != shape or slot.dtype != self.cpu_buf[key].dtype:
+            slot = torch.empty(shape, dtype=self.cpu_buf[key].dtype, device=self.device)
+            gpu_tensors[self.name][self.layer_key] = slot
+        side = load_stream()
+        side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
+        with torch.cuda.stream(side):
+            slot.copy_(self.cpu_buf[key][: slot.numel()].view(shape), non_blocking=True)
+            slot.record_stream(side)
+        return slot
+
+    def load_async_wait(self) -> None:
+        if self._is_resident_now() and not self.is_offload_enabled:
+            return
+        if not _streams:
+            return
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(load_stream())
+        cur.wait_stream(offload_stream())
+        if self.load_completed_event is not None:
+            self.load_completed_event.wait()
+            self.load_completed_event = None

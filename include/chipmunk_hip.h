@@ -1,0 +1,133 @@
+/*
+ * chipmunk_hip.h -- C ABI of the MI355X (gfx950) column-sparse DiT hot path.
+ *
+ * One entry point per operator of the reference's PyTorch operator surface
+ * (`TORCH_LIBRARY(chipmunk)`, reference csrc/chipmunk.cpp:45-60).  Plain pointers and sizes only:
+ * no torch types cross this boundary.  The torch-side registration that turns these back into
+ * `torch.ops.chipmunk.*` lives in chipmunk_amd/csrc/torch_registry.cpp; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; bf16 tensors are raw 16-bit storage;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); calls only enqueue work;
+ *   - return value 0 = success; non-zero = error, message available from chipmunk_last_error();
+ *     nothing is ever written to stderr and the process is never exited (the reference exit()s in
+ *     csrc/mlp/csp_mlp_mm2_and_scatter_add.cu:15-42; that behaviour is deliberately not reproduced);
+ *   - strides are in ELEMENTS for dims (batch, head, token); the head dimension (128) is contiguous.
+ */
+#ifndef CHIPMUNK_HIP_H
+#define CHIPMUNK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHIPMUNK_OK 0
+#define CHIPMUNK_ERR_INVALID 1 /* bad shape / argument (the reference raises TORCH_CHECK / std::runtime_error) */
+#define CHIPMUNK_ERR_LAUNCH 2  /* HIP launch failure */
+
+/* element types for the dtype-generic ops (reference dispatches bf16/fp16/fp32: topk_indices.cu:171-215) */
+#define CHIPMUNK_DTYPE_BF16 0
+#define CHIPMUNK_DTYPE_FP16 1
+#define CHIPMUNK_DTYPE_FP32 2
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *chipmunk_last_error(void);
+/* ABI version of this library (bumped on signature changes). */
+int chipmunk_abi_version(void);
+
+/* ---------------------------------------------------------------- column-sparse attention
+ * Replaces chipmunk::csp_attn (reference csrc/attn/csp_attn.cu:315-423; schema csrc/chipmunk.cpp:52).
+ * For every (b, h, 192-query group g): J = indices[b,h,g,0:counts[b,h,g]];
+ *   o[b,h,i,:] += o_scale * sum_{j in J} softmax_j(q_i.k_j / sqrt(128)) v_j     for i in group g
+ * q,o: [B,H,Nq,128] bf16 (strided); k,v: [B,H,Nk,128] bf16 (strided); indices [B,H,G,idx_stride] int32
+ * (G = ceil(Nq/192), row stride idx_stride >= max count); counts [B,H,G] int32; o_scale in {1,-1}.
+ * The accumulate is bf16: o_new = bf16(o_old + bf16(o_scale*result)) (csp_attn.cu:294-300). */
+int chipmunk_csp_attn(const void *q, const void *k, const void *v, void *o, const int64_t q_strides[3],
+                      const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+                      const int32_t *indices, const int32_t *counts, int B, int H, int Nq, int Nk, int idx_stride,
+                      int o_scale, void *stream);
+
+/* Replaces chipmunk::csp_128_attn (reference csrc/attn/csp_128_attn.cu:355-461; schema csrc/chipmunk.cpp:53).
+ * Same math, out of place into `o` (contiguous [B,H,Nq,128] bf16, fully overwritten), contiguous q/k/v. */
+int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,
+                          const int32_t *counts, int B, int H, int Nq, int Nk, int idx_stride, void *stream);
+
+/* Replaces chipmunk::dense_attn (reference csrc/attn/dense_attn.cu:246-372; schema csrc/chipmunk.cpp:54).
+ * o [B,H,Nq,128] bf16 contiguous; l [B,H,Nq] fp32 = 1 / sum_j exp(q_i.k_j / sqrt(128)) (dense_attn.cu:225-227). */
+int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                        const int64_t k_strides[3], const int64_t v_strides[3], void *o, float *l, int B, int H,
+                        int Nq, int Nk, void *stream);
+
+/* Replaces chipmunk::dense_colsum_attn (reference csrc/attn/dense_colsum_attn.cu:521-668; schema chipmunk.cpp:55).
+ * p [B,H,Nq] fp32 = previous step's l.  cs [B,H,ceil(Nq/192),cs_stride] bf16:
+ *   cs[b,h,g,j] = sum_{i in group g} bf16(exp(s_ij - m_i)) * bf16(exp(m_i) * p_i)   for j < Nk
+ * (dense_colsum_attn.cu:267-277); columns j >= Nk are left untouched. */
+int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                               const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
+                               void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride, void *stream);
+
+/* ---------------------------------------------------------------- column-sparse MLP
+ * Replaces chipmunk::csp_mlp_mm1 (reference csrc/mlp/csp_mlp_mm1.cu:625-702; schema csrc/chipmunk.cpp:47).
+ * For 128-row group g and packed column j < counts[g]:
+ *   c[m,j] = bf16( gelu_tanh(a[m,:].b[idx[g,j],:] + bias[idx[g,j]]) - pa_cache[idx[g,j], m] )
+ * a [M,K], b [F,K] (= fc1.weight), c [M,F] (packed; columns >= counts[g] untouched), bias [F],
+ * pa_cache [F,M] (column-major activation cache), indices [M/128,F] int32, counts [M/128] int32; all bf16.
+ * Requires M % 128 == 0, K % 64 == 0 (csp_mlp_mm1.cu:215,230); counts need only be multiples of 16. */
+int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const void *bias, const void *pa_cache,
+                         const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream);
+
+/* Replaces chipmunk::csp_mlp_mm2_and_scatter_add (reference csrc/mlp/csp_mlp_mm2_and_scatter_add.cu:96-259 plus the
+ * Triton GEMM src/chipmunk/triton/csp_mlp_mm2.py:26-129; schema csrc/chipmunk.cpp:48).
+ *  (i)  unpacked_colmajor[idx[g,c], g*128 + r] += packed[g*128 + r, c]           (bf16 add, c < counts[g])
+ *  (ii) mma_c[m,:] = bf16(sum_{c<counts[g]} mma_a[m,c] * mma_b[idx[g,c],:]) + mma_c[m,:]
+ * packed, mma_a [M,F]; unpacked_colmajor [F,M]; mma_b [F,N2] (= fc2.weight.T contiguous); mma_c [M,N2].
+ * `num_sms_scatter_add` is the reference's SM-partition hint (kept for signature parity; ignored). */
+int chipmunk_csp_mlp_mm2_and_scatter_add(const void *packed, void *unpacked_colmajor, const int32_t *indices,
+                                         const int32_t *counts, const void *mma_a, const void *mma_b, void *mma_c,
+                                         int M, int F, int N2, int num_sms_scatter_add, void *stream);
+
+/* Replaces chipmunk::csp_scatter_add (reference csrc/indexed_io/scatter_add.cu:102-181; schema chipmunk.cpp:59): (i) only. */
+int chipmunk_csp_scatter_add(const void *packed, void *unpacked_colmajor, const int32_t *indices,
+                             const int32_t *counts, int M, int F, int num_sms, void *stream);
+
+/* GEMM (ii) alone: the native counterpart of the reference's Triton csp_mlp_mm2 (triton/csp_mlp_mm2.py:104-129). */
+int chipmunk_csp_mlp_mm2(const void *mma_a, const void *mma_b, void *mma_c, const int32_t *indices,
+                         const int32_t *counts, int M, int F, int N2, void *stream);
+
+/* ---------------------------------------------------------------- indexed IO
+ * Replaces chipmunk::topk_indices (reference csrc/indexed_io/topk_indices.cu:145-218; schema chipmunk.cpp:58).
+ * activation [B*R, C] of `dtype`; indices [B*R, C] int32; counts [B*R] int32.  Threshold = element
+ * int(1024*sparsity) of the ascending-sorted first 1024 values of the row (:94-101); keep x >= threshold.
+ * Deterministic canonical order (a refinement of the reference's atomics-dependent order): kept columns
+ * ascending, then padding up to `multiple_of` with "last rejected column of residue t (mod 1024)" for ascending t.
+ * random_amount > 0 (cuRAND in the reference) keeps extra columns chosen by a counter-based hash. */
+int chipmunk_topk_indices(const void *activation, int dtype, int32_t *indices, int32_t *counts, int rows, int cols,
+                          double sparsity_amount, int multiple_of, double random_amount, void *stream);
+
+/* Replaces chipmunk::mask_to_indices (reference csrc/indexed_io/mask_to_indices.cu:92-143; schema chipmunk.cpp:60).
+ * mask [rows, n] bool bytes; indices [rows, pad_n] int32; counts [rows] int32.  Bit-exact order: True columns of
+ * residue class t (mod 32) ascending for t = 0..31, then the first False columns ascending up to multiple_of. */
+int chipmunk_mask_to_indices(const void *mask, int32_t *indices, int32_t *counts, int64_t rows, int n, int pad_n,
+                             int multiple_of, void *stream);
+
+/* Fused variant: same output from the bit-packed mask (reference ops/bitpack.py:4-40 layout,
+ * little-endian, flat) without materialising the bool mask.  Requires n % 8 == 0. */
+int chipmunk_packed_mask_to_indices(const void *packed, int32_t *indices, int32_t *counts, int64_t rows, int n,
+                                    int pad_n, int multiple_of, void *stream);
+
+/* Replaces chipmunk::copy_indices (reference csrc/indexed_io/copy_indices.cu:82-154; schema chipmunk.cpp:57).
+ * dst[b,row,idx] = src[b,row,idx] for the first counts[b,row/R] entries of inds[b,row/R,:]; elem_size 2 or 4. */
+int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const int32_t *counts, int B, int M, int R,
+                          int F, int elem_size, void *stream);
+
+/* bitpack / bitunpack (reference src/chipmunk/ops/bitpack.py:4-69): 8 bools -> 1 byte, little-endian, flat. */
+int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream);
+int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHIPMUNK_HIP_H */

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    import oracle
+    oracle.build()
+    yield
+
+
+@pytest.fixture()
+def fresh_config():
+    """Restore GLOBAL_CONFIG and the shared LayerCounter around a test."""
+    from chipmunk_amd.util import config as cfg
+    from chipmunk_amd.util import layer_counter as lc
+    cfg.reset_to_base()
+    lc.singleton.__init__(0, 0)
+    yield cfg.GLOBAL_CONFIG
+    cfg.reset_to_base()
+    lc.singleton.__init__(0, 0)

@@ -1,0 +1,146 @@
+"""GPU parity of the four attention ops against the CPU oracle (calls go torch.ops.chipmunk.* -> C ABI -> HIP).
+
+Tolerances (stated per SURVEY 8c): bf16 outputs atol = rtol = 2e-2 vs the fp32-accumulating oracle; l (fp32) rtol 1e-3;
+cs (bf16 sums of up to 192 bf16 terms, reduction order free) rtol 3e-2 + atol 2e-3.
+"""
+import math
+
+import pytest
+import torch
+
+import oracle
+from helpers import assert_close_bf16, randn_bf16, random_index_sets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import chipmunk_amd  # noqa: F401  (loads the HIP library and registers torch.ops.chipmunk)
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _qkv(B, H, Nq, Nk, seed):
+    return (randn_bf16(B, H, Nq, 128, seed=seed), randn_bf16(B, H, Nk, 128, seed=seed + 1),
+            randn_bf16(B, H, Nk, 128, seed=seed + 2))
+
+
+@pytest.mark.parametrize("n", [384, 512, 1000, 1984])
+def test_dense_attn_vs_oracle_and_sdpa(dev, n):
+    """reference tests/test_dense_attn.py:29-36 (vs SDPA) + the oracle; ragged n exercises the masked last group/tile."""
+    q, k, v = _qkv(1, 3, n, n, seed=n)
+    o_ref, l_ref = oracle.dense_attn(q, k, v)
+    o, l = torch.ops.chipmunk.dense_attn(q.to(dev), k.to(dev), v.to(dev))
+    assert o.shape == q.shape and l.shape == (1, 3, n, 1) and l.dtype == torch.float32
+    assert_close_bf16(o, o_ref, what="dense_attn o")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    sdpa = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert_close_bf16(o, sdpa, what="dense_attn vs SDPA")
+
+
+def test_dense_attn_strided_inputs(dev):
+    """reference tests/test_dense_attn.py:18-27: [B,N,H,D] storage viewed as [B,H,N,D]."""
+    B, H, N = 1, 4, 576
+    base = [randn_bf16(B, N, H, 128, seed=s).to(dev) for s in (1, 2, 3)]
+    q, k, v = [t.permute(0, 2, 1, 3) for t in base]
+    assert not q.is_contiguous()
+    o, l = torch.ops.chipmunk.dense_attn(q, k, v)
+    o_ref, l_ref = oracle.dense_attn(q.cpu().contiguous(), k.cpu().contiguous(), v.cpu().contiguous())
+    assert_close_bf16(o, o_ref, what="strided dense_attn")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+
+
+@pytest.mark.parametrize("n", [4480, 4592])
+def test_csp_attn_identity_indices_is_sdpa(dev, n):
+    """reference tests/test_csp_attn.py:30-38: identity indices, counts = n, into a zero o => SDPA."""
+    H = 2
+    q, k, v = _qkv(1, H, n, n, seed=7)
+    G = math.ceil(n / 192)
+    inds = torch.arange(n, dtype=torch.int32).expand(1, H, G, n).contiguous()
+    counts = torch.full((1, H, G), n, dtype=torch.int32)
+    o = torch.zeros_like(q).to(dev)
+    torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), o, inds.to(dev), counts.to(dev), 1)
+    sdpa = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert_close_bf16(o, sdpa, what="csp_attn identity")
+
+
+@pytest.mark.parametrize("o_scale", [1, -1])
+@pytest.mark.parametrize("n,count", [(960, 224), (1100, 336)])
+def test_csp_attn_inplace_random_indices(dev, n, count, o_scale):
+    """in-place accumulate with non-identity index sets and both signs (no reference test covers this)."""
+    H = 2
+    q, k, v = _qkv(1, H, n, n, seed=11)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, count, n, seed=5)
+    o0 = randn_bf16(1, H, n, 128, seed=99)
+    o_ref = o0.clone()
+    oracle.csp_attn(q, k, v, o_ref, inds, counts, o_scale)
+    o = o0.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), o, inds.to(dev), counts.to(dev), o_scale)
+    assert_close_bf16(o, o_ref, atol=3e-2, what="csp_attn in place")
+
+
+def test_csp_attn_strided_qkv(dev):
+    n, H, count = 768, 3, 224
+    base = [randn_bf16(1, n, H, 128, seed=s) for s in (21, 22, 23)]
+    q, k, v = [t.permute(0, 2, 1, 3) for t in base]
+    G = n // 192
+    inds, counts = random_index_sets(1, H, G, n, count, n, seed=6)
+    o_ref = torch.zeros(1, H, n, 128, dtype=torch.bfloat16)
+    oracle.csp_attn(q, k, v, o_ref, inds, counts, 1)
+    o = torch.zeros(1, n, H, 128, dtype=torch.bfloat16, device=dev).permute(0, 2, 1, 3)
+    torch.ops.chipmunk.csp_attn(*[t.to(dev).permute(0, 2, 1, 3) for t in base], o, inds.to(dev), counts.to(dev), 1)
+    assert_close_bf16(o, o_ref, what="strided csp_attn")
+
+
+@pytest.mark.parametrize("n,nk,count", [(768, 768, 256), (1152, 1100, 384), (960, 960, 64)])
+def test_csp_128_attn_random_indices(dev, n, nk, count):
+    H = 2
+    q, k, v = _qkv(1, H, n, nk, seed=31)
+    G = n // 192
+    inds, counts = random_index_sets(1, H, G, nk, count, n, seed=8)
+    # ragged per-group counts, multiples of 16 (the kernel accepts any multiple; the reference wants 128)
+    counts[0, 0, 0] = max(16, count - 48)
+    counts[0, 1, G - 1] = max(16, count - 16)
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what="csp_128_attn")
+
+
+def test_csp_attn_full_minus_sparse_roundtrip(dev):
+    """Size-independent property used by the module: o_cache = o - sparse; o_cache + sparse == o (bf16 tolerance)."""
+    n, H, count = 4352, 4, 672  # FLUX C2 shape per head
+    q, k, v = _qkv(1, H, n, n, seed=41)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, count, n, seed=9)
+    qd, kd, vd, indd, cntd = [t.to(dev) for t in (q, k, v, inds, counts)]
+    o, _ = torch.ops.chipmunk.dense_attn(qd, kd, vd)
+    cache = o.clone()
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, cache, indd, cntd, -1)
+    back = cache.clone()
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, back, indd, cntd, 1)
+    assert_close_bf16(back, o, atol=3e-2, what="cache roundtrip")
+
+
+@pytest.mark.parametrize("n", [576, 1000])
+def test_dense_colsum_attn(dev, n):
+    """reference tests/test_dense_colsum_attn.py:13-36 (fp32 column-sum formula) + the oracle."""
+    H = 2
+    q, k, v = _qkv(1, H, n, n, seed=51)
+    # a second, correlated step (q' = q + 0.1 eps) as in the real pipeline
+    q2 = (q.float() + 0.1 * torch.randn(q.shape, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16)
+    _, l0 = oracle.dense_attn(q, k, v)
+    o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(q2, k, v, l0)
+    o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))
+    G = math.ceil(n / 192)
+    assert cs.shape == (1, H, G, n) and cs.dtype == torch.bfloat16
+    assert_close_bf16(o, o_ref, what="colsum o")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what="colsum cs vs oracle")
+    # the reference test's fp32 formula: p = exp(logits) * l_prev, summed over each 192-row group
+    logits = (q2.float() @ k.float().transpose(-1, -2)) / math.sqrt(128)
+    p = torch.exp(logits) * l0
+    pad = G * 192 - n
+    p = torch.nn.functional.pad(p, (0, 0, 0, pad)).view(1, H, G, 192, n).sum(3)
+    assert_close_bf16(cs, p, atol=4e-3, rtol=4e-2, what="colsum cs vs fp32 formula")

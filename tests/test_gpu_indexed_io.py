@@ -1,0 +1,106 @@
+"""GPU parity of the indexed-IO ops against the CPU oracle: integer work, bit-exact."""
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import chipmunk_amd  # noqa: F401
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand_mask(shape, density, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) < density
+
+
+def _check_m2i(dev, mask, multiple_of, pad_to):
+    ref_i, ref_c = oracle.mask_to_indices(mask, multiple_of, pad_to)
+    got_i, got_c = torch.ops.chipmunk.mask_to_indices(mask.to(dev), multiple_of, pad_to)
+    assert got_i.shape == ref_i.shape and got_i.dtype == torch.int32
+    assert torch.equal(got_c.cpu(), ref_c)
+    n_written = ref_c.clamp(max=mask.shape[-1])  # a row can run out of False columns for padding
+    live = torch.arange(ref_i.shape[-1])[None, None, None, :] < n_written[..., None]
+    live &= ref_i >= 0
+    assert torch.equal(got_i.cpu()[live], ref_i[live]), "index order must match the reference's lane-interleaved order"
+    return got_i, got_c
+
+
+@pytest.mark.parametrize("shape,density", [((1, 2, 3, 4352), 0.15), ((1, 3, 5, 4000), 0.06), ((2, 2, 4, 1000), 0.5),
+                                           ((1, 1, 2, 77), 0.3), ((1, 2, 2, 7488), 0.07)])
+def test_mask_to_indices(dev, shape, density):
+    _check_m2i(dev, _rand_mask(shape, density, seed=shape[-1]), 128, 192)
+
+
+def test_mask_to_indices_edge_rows(dev):
+    n = 1536
+    mask = torch.zeros(1, 1, 4, n, dtype=torch.bool)
+    mask[0, 0, 1] = True                 # everything kept: no padding possible
+    mask[0, 0, 2, ::3] = True            # count 512 -> already a multiple of 128
+    mask[0, 0, 3, 5] = True              # one True -> 127 padding columns
+    _check_m2i(dev, mask, 128, 192)
+    _check_m2i(dev, mask, 112, 192)
+
+
+def test_packed_mask_to_indices_equals_unpack_then_m2i(dev):
+    import chipmunk_amd
+    shape = (1, 3, 4, 4352)
+    mask = _rand_mask(shape, 0.07, seed=3).to(dev)
+    packed, shp = chipmunk_amd.ops.bitpack(mask)
+    ref_p, _ = oracle.bitpack(mask.cpu())
+    assert torch.equal(packed.cpu(), ref_p)
+    assert torch.equal(chipmunk_amd.ops.bitunpack(packed, shp).cpu(), mask.cpu())
+    i1, c1 = torch.ops.chipmunk.mask_to_indices(mask, 128, 192)
+    i2, c2 = chipmunk_amd.ops.packed_mask_to_indices(packed, shp, 128, 192)
+    assert torch.equal(c1, c2)
+    live = torch.arange(i1.shape[-1], device=dev)[None, None, None, :] < c1[..., None]
+    assert torch.equal(i1[live], i2[live])
+
+
+def test_bitpack_unaligned_length(dev):
+    import chipmunk_amd
+    mask = _rand_mask((3, 37), 0.4, seed=9).to(dev)  # 111 bits: not a multiple of 8
+    packed, shp = chipmunk_amd.ops.bitpack(mask)
+    ref_p, _ = oracle.bitpack(mask.cpu())
+    assert torch.equal(packed.cpu(), ref_p)
+    assert torch.equal(chipmunk_amd.ops.bitunpack(packed, shp).cpu(), mask.cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("sparsity,multiple_of", [(0.7, 256), (0.9, 112), (0.0, 256), (1.0, 256)])
+def test_topk_indices(dev, dtype, sparsity, multiple_of):
+    B, R, C = 1, 5, 12288  # FLUX: [1, 30, 12288]
+    g = torch.Generator().manual_seed(17)
+    act = torch.randn(B, R, C, generator=g).abs().to(dtype)
+    ref_i = torch.full((B, R, C), -7, dtype=torch.int32)
+    ref_c = torch.zeros(B, R, dtype=torch.int32)
+    oracle.topk_indices(act, ref_i, ref_c, sparsity, multiple_of, 0.0)
+    got_i = torch.full((B, R, C), -7, dtype=torch.int32, device=dev)
+    got_c = torch.zeros(B, R, dtype=torch.int32, device=dev)
+    torch.ops.chipmunk.topk_indices(act.to(dev), got_i, got_c, sparsity, multiple_of, 0.0)
+    assert torch.equal(got_c.cpu(), ref_c)
+    assert torch.equal(got_i.cpu(), ref_i), "kept set, canonical order and padding columns must be bit-exact"
+    if 0 < sparsity < 1:  # the kept set is exactly {x >= threshold}; threshold from the first 1024 columns
+        thr = act[0, 0, :1024].float().sort().values[int(1024 * torch.tensor(sparsity, dtype=torch.float32).item())]
+        kept = set(torch.nonzero(act[0, 0].float() >= thr).flatten().tolist())
+        assert kept.issubset(set(got_i[0, 0, :got_c[0, 0]].cpu().tolist()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_copy_indices(dev, dtype):
+    B, M, R, F = 2, 3, 2, 512
+    src = torch.randn(B, M * R, F).to(dtype)
+    dst = torch.randn(B, M * R, F).to(dtype)
+    counts = torch.tensor([[16, 100, 512], [0, 7, 256]], dtype=torch.int32)
+    inds = torch.stack([torch.stack([torch.randperm(F, generator=torch.Generator().manual_seed(b * 10 + m)).int()
+                                     for m in range(M)]) for b in range(B)])
+    ref = dst.clone()
+    oracle.copy_indices(src, ref, inds, counts)
+    out = dst.clone().to(dev)
+    torch.ops.chipmunk.copy_indices(src.to(dev), out, inds.to(dev), counts.to(dev))
+    assert torch.equal(out.cpu(), ref)

@@ -1,0 +1,119 @@
+"""GPU parity of the column-sparse MLP ops against the CPU oracle (torch.ops.chipmunk.* -> C ABI -> HIP)."""
+import pytest
+import torch
+
+import oracle
+from helpers import assert_close_bf16, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import chipmunk_amd  # noqa: F401
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _index_rows(G, F, counts, seed):
+    g = torch.Generator().manual_seed(seed)
+    inds = torch.full((G, F), -1, dtype=torch.int32)
+    for i in range(G):
+        inds[i, :counts[i]] = torch.randperm(F, generator=g)[:counts[i]].to(torch.int32)
+    return inds
+
+
+def _uniform_bf16(*shape, seed, lo=-0.5, hi=0.5):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * (hi - lo) + lo).to(torch.bfloat16)
+
+
+def test_mm1_known_answer_reversed_identity(dev):
+    """The reference's own mm1 check (csp_mlp_mm1.cu:458-486,590-602): reversed identity indices, U(-0.5,0.5) data,
+    abs tolerance 0.1 -- at a reduced shape so the CPU side finishes in seconds."""
+    M, K, F = 256, 512, 1024
+    a, b = _uniform_bf16(M, K, seed=42), _uniform_bf16(F, K, seed=43)
+    bias, cache = _uniform_bf16(F, seed=44), _uniform_bf16(F, M, seed=45)
+    inds = torch.arange(F - 1, -1, -1, dtype=torch.int32).expand(M // 128, F).contiguous()
+    counts = torch.full((M // 128,), F, dtype=torch.int32)
+    c_ref = torch.zeros(M, F, dtype=torch.bfloat16)
+    oracle.csp_mlp_mm1(a, b, c_ref, bias, cache, inds, counts)
+    c = torch.zeros(M, F, dtype=torch.bfloat16, device=dev)
+    torch.ops.chipmunk.csp_mlp_mm1(a.to(dev), b.to(dev), c, bias.to(dev), cache.to(dev), inds.to(dev), counts.to(dev))
+    assert (c.float().cpu() - c_ref.float()).abs().max() < 0.1
+    assert_close_bf16(c, c_ref, what="mm1 known answer")
+    # the in-tree CPU formula directly (csp_mlp_mm1.cu:411-424)
+    ref = torch.nn.functional.gelu(a.float() @ b.float().T + bias.float(), approximate="tanh") - cache.float().T
+    assert_close_bf16(c, ref.flip(1), what="mm1 vs torch formula")
+
+
+@pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768])])
+def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts):
+    a, b = randn_bf16(M, K, seed=1, scale=0.5), randn_bf16(F, K, seed=2, scale=0.1)
+    bias, cache = randn_bf16(F, seed=3, scale=0.2), randn_bf16(F, M, seed=4, scale=0.3)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    inds = _index_rows(M // 128, F, counts, seed=5)
+    sentinel = 7.0
+    c_ref = torch.full((M, F), sentinel, dtype=torch.bfloat16)
+    oracle.csp_mlp_mm1(a, b, c_ref, bias, cache, inds, cnt)
+    c = torch.full((M, F), sentinel, dtype=torch.bfloat16, device=dev)
+    torch.ops.chipmunk.csp_mlp_mm1(a.to(dev), b.to(dev), c, bias.to(dev), cache.to(dev), inds.to(dev), cnt.to(dev))
+    assert_close_bf16(c, c_ref, what="mm1")
+    for g, n in enumerate(counts):  # columns past counts[g] are untouched
+        assert (c[g * 128:(g + 1) * 128, n:].float() == sentinel).all()
+
+
+@pytest.mark.parametrize("M,F,counts", [(256, 512, [64, 192]), (384, 1024, [1024, 8, 320])])
+def test_scatter_add(dev, M, F, counts):
+    packed = randn_bf16(M, F, seed=11)
+    unpacked = randn_bf16(F, M, seed=12)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    inds = _index_rows(M // 128, F, counts, seed=13)
+    ref = unpacked.clone()
+    oracle.csp_scatter_add(packed, ref, inds, cnt)
+    out = unpacked.clone().to(dev)
+    torch.ops.chipmunk.csp_scatter_add(packed.to(dev)[None], out[None], inds.to(dev)[None], cnt.to(dev)[None], 6)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "scatter_add must be bit-exact"
+
+
+@pytest.mark.parametrize("M,F,N2,counts", [(256, 512, 256, [64, 192]), (384, 1024, 384, [512, 8, 328]),
+                                           (128, 512, 768, [512])])
+def test_mm2_and_scatter_add(dev, M, F, N2, counts):
+    packed = randn_bf16(M, F, seed=21, scale=0.2)
+    # columns past the count hold garbage in the real pipeline (torch.empty): make sure they are never read
+    for g, n in enumerate(counts):
+        packed[g * 128:(g + 1) * 128, n:] = float("nan")
+    unpacked = randn_bf16(F, M, seed=22)
+    w2t = randn_bf16(F, N2, seed=23, scale=0.1)
+    out0 = randn_bf16(M, N2, seed=24)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    inds = _index_rows(M // 128, F, counts, seed=25)
+    unp_ref, out_ref = unpacked.clone(), out0.clone()
+    oracle.csp_mlp_mm2_and_scatter_add(packed, unp_ref, inds, cnt, packed, w2t, out_ref)
+    unp, out = unpacked.clone().to(dev), out0.clone().to(dev)
+    pk = packed.to(dev)
+    torch.ops.chipmunk.csp_mlp_mm2_and_scatter_add(pk[None], unp[None], inds.to(dev)[None], cnt.to(dev)[None], pk[None],
+                                                   w2t.to(dev)[None], out[None], 6, 0)
+    assert torch.equal(unp.cpu().view(torch.int16), unp_ref.view(torch.int16))
+    assert_close_bf16(out, out_ref, what="mm2")
+
+
+def test_run_e2e_matches_dense_delta(dev):
+    """ops.mlp end to end: with ALL columns selected the sparse step must reproduce the dense MLP on the new input
+    (cache + delta == fresh activations), the identity the whole method rests on (modules/mlp.py:51-116)."""
+    import chipmunk_amd
+    M, K, F = 256, 256, 1024
+    x0, x1 = randn_bf16(M, K, seed=31), randn_bf16(M, K, seed=32)
+    w1, b1 = randn_bf16(F, K, seed=33, scale=0.06), randn_bf16(F, seed=34, scale=0.1)
+    w2, b2 = randn_bf16(K, F, seed=35, scale=0.03), randn_bf16(K, seed=36, scale=0.1)
+    x0d, x1d, w1d, b1d, w2d, b2d = [t.to(dev) for t in (x0, x1, w1, b1, w2, b2)]
+    act0 = torch.nn.functional.gelu(x0d @ w1d.T + b1d, approximate="tanh")
+    out_cache = (act0 @ w2d.T + b2d).contiguous()
+    act_T = act0.T.contiguous()
+    inds = torch.arange(F, dtype=torch.int32, device=dev).expand(M // 128, F).contiguous()
+    cnt = torch.full((M // 128,), F, dtype=torch.int32, device=dev)
+    chipmunk_amd.ops.mlp(x1d, w1d, b1d, w2d.T.contiguous(), inds, cnt, act_T, out_cache, 6)
+    act1 = torch.nn.functional.gelu(x1d @ w1d.T + b1d, approximate="tanh")
+    ref = act1 @ w2d.T + b2d
+    assert_close_bf16(act_T.T, act1, atol=3e-2, what="activation cache after scatter-add")
+    assert_close_bf16(out_cache, ref, atol=6e-2, rtol=3e-2, what="sparse step output")
