@@ -72,6 +72,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 // ---- host-side error plumbing (thread-local message, see chipmunk_last_error) ----
 void chipmunk_set_error(const char *fmt, ...);
+int chipmunk_get_option(const char *name);
 #define CM_CHECK(cond, ...)                    \
     do {                                       \
         if (!(cond)) {                         \

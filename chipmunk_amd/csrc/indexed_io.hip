@@ -176,25 +176,32 @@ __device__ __forceinline__ float hash_uniform(uint32_t row, uint32_t col) {
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
-// block-wide ordered compaction step: returns this thread's output slot (or -1) and advances *base
+// Block-wide ordered compaction step for a 1024-thread workgroup (16 waves): returns this thread's output slot (or
+// -1) and advances `base`.  One ballot + popcount per wave, the 16 wave totals are scanned through LDS.
 __device__ __forceinline__ int compact_slot(bool keep, int lane, int w, uint32_t *wave_tot, int &base) {
     const unsigned long long bal = __ballot(keep);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wave_tot[w] = __popcll(bal);
     __syncthreads();
-    int off = base;
-    for (int i = 0; i < w; ++i) off += wave_tot[i];
-    const int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    int off = base, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = wave_tot[i];
+        off += i < w ? c : 0;
+        tot += c;
+    }
     __syncthreads();
     base += tot;
     return keep ? off + before : -1;
 }
 
+// One 1024-thread workgroup per row (the reference's launch shape, topk_indices.cu:200-213).  The quantile of the
+// 1024-column sample is found by rank counting (each thread ranks its own sample against all 1024 through LDS
+// broadcasts) instead of the reference's CUB block merge sort: same element, ~1 us.
 template <typename T>
-__global__ __launch_bounds__(256) void topk_indices_kernel(const TopkParams p) {
-    __shared__ float sample[1024];
-    __shared__ int last_invalid[1024];
-    __shared__ uint32_t wave_tot[4];
+__global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ float thr_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x;
     const T *x = (const T *)p.act + (int64_t)row * p.cols;
@@ -202,64 +209,100 @@ __global__ __launch_bounds__(256) void topk_indices_kernel(const TopkParams p) {
     const int cols = p.cols;
 
     if (p.quantile == 0.f) {  // keep everything (topk_indices.cu:51-59)
-        for (int c = tid; c < cols; c += 256) out[c] = c;
+        for (int c = tid; c < cols; c += 1024) out[c] = c;
         if (tid == 0) p.counts[row] = cols;
         return;
     }
     if (p.quantile == 1.f) {  // keep nothing (topk_indices.cu:60-69)
-        for (int c = tid; c < cols; c += 256) out[c] = -1;
+        for (int c = tid; c < cols; c += 1024) out[c] = -1;
         if (tid == 0) p.counts[row] = 0;
         return;
     }
-    // ---- threshold = element int(1024*q) of the ascending-sorted first 1024 values (topk_indices.cu:91-101)
-    for (int i = tid; i < 1024; i += 256) sample[i] = load_as_float<T>(x, i);
-    __syncthreads();
-    for (int k = 2; k <= 1024; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < 1024; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const float a = sample[i], b = sample[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        sample[i] = b;
-                        sample[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
+    // ---- threshold = element int(1024*q) of the ascending-sorted first 1024 values (topk_indices.cu:91-101).
+    //      Order statistic by bitwise bisection inside ONE wave (16 sample keys per lane, no barriers, no sort):
+    //      result = largest v with #{keys < v} <= k, built from the most significant bit down.
+    if (w == 0) {
+        uint32_t key[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t u = __float_as_uint(load_as_float<T>(x, lane + 64 * j));
+            key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned map
         }
-    const float thr = sample[(int)(1024 * p.quantile)];
-    for (int i = tid; i < 1024; i += 256) last_invalid[i] = -1;
+        const int k = (int)(1024 * p.quantile);
+        uint32_t res = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = res | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cnt += key[j] < cand ? 1 : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (cnt <= k) res = cand;
+        }
+        const uint32_t u = (res & 0x80000000u) ? (res & 0x7fffffffu) : ~res;
+        if (lane == 0) thr_s = __uint_as_float(u);
+    }
     __syncthreads();
+    const float thr = thr_s;
 
-    // ---- ordered compaction of kept columns; remember the last rejected column of every residue class mod 1024
+    // ---- ordered compaction of kept columns, 16 x 1024 columns per pass: every thread tests up to 16 columns
+    //      (t, t+1024, ...: all loads in flight at once), one ballot per (chunk, wave), ONE scan of the 256 wave totals.
+    __shared__ uint32_t tot[16 * 16 + 1];
     int base = 0;
-    for (int c0 = 0; c0 < cols; c0 += 256) {
-        const int c = c0 + tid;
-        bool keep = false;
-        if (c < cols) {
-            keep = load_as_float<T>(x, c) >= thr;
-            if (!keep && p.random_amount > 0.f) keep = hash_uniform(row, c) < p.random_amount;
-            if (!keep) last_invalid[c & 1023] = c;  // ascending c per slot => ends as the last rejected column
+    int my_last_invalid = -1;
+    for (int pass0 = 0; pass0 < cols; pass0 += 16 * 1024) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = pass0 + j * 1024 + tid;
+            v[j] = c < cols ? load_as_float<T>(x, c) : 0.f;
         }
-        const int slot = compact_slot(keep, lane, w, wave_tot, base);
-        if (slot >= 0) out[slot] = c;
+        uint32_t keepbits = 0;
+        int before[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = pass0 + j * 1024 + tid;
+            bool keep = false;
+            if (c < cols) {
+                keep = v[j] >= thr;
+                if (!keep && p.random_amount > 0.f) keep = hash_uniform(row, c) < p.random_amount;
+                if (!keep) my_last_invalid = c;  // ascending c per thread => ends as the last rejected column
+            }
+            const unsigned long long bal = __ballot(keep);
+            before[j] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) tot[j * 16 + w] = __popcll(bal);
+            keepbits |= keep ? (1u << j) : 0u;
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the 256 (chunk, wave) totals by one wave, 4 entries per lane
+            uint32_t a0 = tot[tid * 4], a1 = tot[tid * 4 + 1], a2 = tot[tid * 4 + 2], a3 = tot[tid * 4 + 3];
+            uint32_t sum = a0 + a1 + a2 + a3, incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t excl = incl - sum;
+            tot[tid * 4] = excl, tot[tid * 4 + 1] = excl + a0, tot[tid * 4 + 2] = excl + a0 + a1;
+            tot[tid * 4 + 3] = excl + a0 + a1 + a2;
+            if (tid == 63) tot[256] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (keepbits & (1u << j)) out[base + tot[j * 16 + w] + before[j]] = pass0 + j * 1024 + tid;
+        base += tot[256];
+        __syncthreads();
     }
     const int kept = base;
     const int mod = kept % p.multiple_of;
-    int pad = mod == 0 ? 0 : p.multiple_of - mod;
+    const int pad = mod == 0 ? 0 : p.multiple_of - mod;
     if (tid == 0) p.counts[row] = kept + pad;
-    __syncthreads();
     // ---- padding candidates in ascending residue order (a deterministic choice among the reference's outcomes)
-    for (int t0 = 0; t0 < 1024 && pad > 0; t0 += 256) {
-        const int cand = last_invalid[t0 + tid];
+    if (pad > 0) {
         int pbase = 0;
-        const int slot = compact_slot(cand != -1, lane, w, wave_tot, pbase);
-        if (slot >= 0 && slot < pad) out[base + slot] = cand;
-        const int used = pbase < pad ? pbase : pad;
-        base += used;
-        pad -= used;
+        const int slot = compact_slot(my_last_invalid != -1, lane, w, wave_tot, pbase);
+        if (slot >= 0 && slot < pad) out[kept + slot] = my_last_invalid;
     }
 }
 
@@ -355,9 +398,9 @@ extern "C" int chipmunk_topk_indices(const void *activation, int dtype, int32_t 
     TopkParams p = {activation, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount};
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case CHIPMUNK_DTYPE_BF16: hipLaunchKernelGGL(topk_indices_kernel<uint16_t>, dim3(rows), dim3(256), 0, s, p); break;
-        case CHIPMUNK_DTYPE_FP16: hipLaunchKernelGGL(topk_indices_kernel<_Float16>, dim3(rows), dim3(256), 0, s, p); break;
-        case CHIPMUNK_DTYPE_FP32: hipLaunchKernelGGL(topk_indices_kernel<float>, dim3(rows), dim3(256), 0, s, p); break;
+        case CHIPMUNK_DTYPE_BF16: hipLaunchKernelGGL(topk_indices_kernel<uint16_t>, dim3(rows), dim3(1024), 0, s, p); break;
+        case CHIPMUNK_DTYPE_FP16: hipLaunchKernelGGL(topk_indices_kernel<_Float16>, dim3(rows), dim3(1024), 0, s, p); break;
+        case CHIPMUNK_DTYPE_FP32: hipLaunchKernelGGL(topk_indices_kernel<float>, dim3(rows), dim3(1024), 0, s, p); break;
         default: CM_CHECK(false, "topk_indices: unsupported dtype code %d", dtype);
     }
     CM_LAUNCH_CHECK();

@@ -13,11 +13,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 256, BK = 64;
-constexpr int A_TILE = BM * BK * 2;   // 16 KiB
-constexpr int B1_TILE = BN * BK * 2;  // 32 KiB (mm1: 256 gathered rows x 64 k)
-constexpr int B2_TILE = BK * BN * 2;  // 32 KiB (mm2: 64 gathered rows x 256 n)
-constexpr int MLP_LDS = 2 * (A_TILE + B1_TILE);
+constexpr int BM = 128;  // rows per workgroup = one sparsity group (reference bm = 128)
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -30,92 +26,162 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x - x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate out of range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Geometry of a k-contiguous operand tile [ROWS][BK] bf16 staged by LDS-DMA:
+//   row stride BK*2 bytes, CPR = BK/8 16-byte chunks per row, one DMA instruction (64 lanes x 16 B) covers RPI rows;
+//   chunk c of row r is stored at chunk c ^ swz(r), swz(r) = (r / RPB) & (CPR-1), RPB = rows per 256-byte bank row:
+//   conflict-free for the ds_read_b128 lane groups of a 32-row MFMA operand fragment.
+template <int BK>
+struct KTile {
+    static constexpr int ROWB = BK * 2, CPR = BK / 8, RPI = 1024 / ROWB, RPB = 256 / ROWB;
+    __device__ static __forceinline__ int swz(int row) { return (row / RPB) & (CPR - 1); }
+    // source element offset inside a row for the lane's stored chunk
+    __device__ static __forceinline__ int src_chunk_elems(int row, int lane) { return ((lane % CPR) ^ swz(row)) << 3; }
+    __device__ static __forceinline__ int lane_row(int inst, int lane) { return inst * RPI + lane / CPR; }
+    __device__ static __forceinline__ bf16x8 frag(const unsigned char *tile, int row, int kk, int lane) {
+        const int c = kk * 2 + (lane >> 5);
+        return *(const bf16x8 *)(tile + row * ROWB + ((c ^ swz(row)) << 4));
+    }
+};
+
+
+// Live-tile map shared by both GEMMs.  The host launches G x NTmax workgroups without knowing the per-group counts
+// (they live in HBM); every workgroup derives the same compact order from them:
+//   * only column tiles below max_g counts[g] are live (a dead workgroup exits in a few hundred cycles);
+//   * the live tiles are split into 8 contiguous chunks, one per XCD (block b runs on XCD b % 8);
+//   * inside a chunk consecutive tiles walk "NR column tiles x all groups": with ascending index lists the tiles of
+//     DIFFERENT groups over the same column-tile position gather overlapping weight rows, so the ~64 workgroups an XCD
+//     runs at once re-use each other's rows (and each group's activation tile) out of that XCD's 4 MiB L2 instead of
+//     re-fetching them through the fabric.  Measured on FLUX shapes: fabric fetch per launch 860 MB -> see DESIGN.md.
+struct TileMap {
+    int g, nt;
+    bool live;
+};
+template <int BN>
+__device__ __forceinline__ TileMap map_tile(const int32_t *counts, int G, int NTmax, int NR) {
+    int cmax = 0;
+    for (int g = 0; g < G; ++g) cmax = max(cmax, counts[g]);
+    const int NTl = min((cmax + BN - 1) / BN, NTmax);
+    const int total = NTl * G;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    TileMap m;
+    m.live = slot < q + (xcd < r ? 1 : 0);
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int per = G * NR;
+    const int nb = t / per, rem = t - nb * per;
+    const int nr = min(NR, NTl - nb * NR);
+    m.g = nr > 0 ? rem / nr : 0;
+    m.nt = nb * NR + (nr > 0 ? rem - m.g * nr : 0);
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------ mm1
 struct Mm1Params {
     const uint16_t *a, *b, *bias, *cache;
     uint16_t *c;
     const int32_t *indices, *counts;
-    int M, K, F, NT;
+    int M, K, F, NT, NR;
 };
 
-// k-contiguous [rows][64] bf16 tile image, row stride 128 B, 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7)
-__device__ __forceinline__ bf16x8 read_kfrag(const unsigned char *tile, int row, int kk, int lane) {
-    const int c = kk * 2 + (lane >> 5);
-    return *(const bf16x8 *)(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-}
-
-__global__ __launch_bounds__(256, 1) void mm1_kernel(const Mm1Params p) {
+template <int BN, int BK, int NST, int WPS>
+__global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
+    using KT = KTile<BK>;
+    constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2, STAGE = A_TILE + B_TILE;
+    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;  // DMA instructions per wave per tile
+    constexpr int NT4 = BN / 64;                                    // 32-wide n tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Al = smem;               // [2][A_TILE]
-    unsigned char *Bl = smem + 2 * A_TILE;  // [2][B1_TILE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
 
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int g = wid / p.NT, nt = wid - g * p.NT;
+    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR);
+    if (!tm.live) return;
+    const int g = tm.g, nt = tm.nt;
     const int cnt = p.counts[g];
     const int n0 = nt * BN;
     if (n0 >= cnt) return;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
     const int32_t *idxg = p.indices + (int64_t)g * p.F;
 
-    // per-lane DMA sources: lane -> (row = inst*8 + lane/8, stored chunk = lane%8), source chunk = stored ^ swizzle(row)
-    int aoff[4], boff[8];
+    int aoff[A_INST], boff[B_INST];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 8 + (lane >> 3);
-        aoff[i] = (g * BM + row) * p.K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = KT::lane_row(w * A_INST + i, lane);
+        aoff[i] = (g * BM + row) * p.K + KT::src_chunk_elems(row, lane);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (w * 8 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < B_INST; ++i) {
+        const int row = KT::lane_row(w * B_INST + i, lane);
         const int j = n0 + row;
         const int key = idxg[j < cnt ? j : n0];  // rows past the count re-read a live row and are never stored
-        boff[i] = key * p.K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        boff[i] = key * p.K + KT::src_chunk_elems(row, lane);
     }
     auto issue = [&](int kb, int buf) {
+        unsigned char *st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(p.a + aoff[i] + kb * BK, Al + buf * A_TILE + (w * 4 + i) * 1024);
+        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BK, st + (w * A_INST + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) glds16(p.b + boff[i] + kb * BK, Bl + buf * B1_TILE + (w * 8 + i) * 1024);
+        for (int i = 0; i < B_INST; ++i) glds16(p.b + boff[i] + kb * BK, st + A_TILE + (w * B_INST + i) * 1024);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int n4 = 0; n4 < 4; ++n4)
+        for (int n4 = 0; n4 < NT4; ++n4)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][n4][r] = 0.f;
 
     const int nkb = p.K / BK;
-    issue(0, 0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nkb) issue(s, s);
+    int buf = 0, nbuf = NST - 1;
     for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kb + 1 < nkb) issue(kb + 1, buf ^ 1);
-        const unsigned char *At = Al + buf * A_TILE;
-        const unsigned char *Bt = Bl + buf * B1_TILE;
+        // tile kb must have landed; the NST-2 younger tiles may stay in flight across the barrier
+        if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1, nbuf);
+        const unsigned char *At = smem + buf * STAGE;
+        const unsigned char *Bt = At + A_TILE;
+        // operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are in flight while the
+        // MFMAs of slice kk issue (left to itself hipcc emits read -> lgkmcnt(0) -> 4 MFMA -> read ...)
+        constexpr int KK = BK / 16;
+        bf16x8 af[2][2], bfr[2][NT4];
+        auto load_frags = [&](int kk, int set) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bfr[4];
+            for (int mt = 0; mt < 2; ++mt) af[set][mt] = KT::frag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[mt] = read_kfrag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
+            for (int n4 = 0; n4 < NT4; ++n4)
+                bfr[set][n4] = KT::frag(Bt, wn * (BN / 2) + n4 * 32 + (lane & 31), kk, lane);
+        };
+        load_frags(0, 0);
 #pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = read_kfrag(Bt, wn * 128 + n4 * 32 + (lane & 31), kk, lane);
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the next slice's reads ahead of this slice's MFMAs
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int n4 = 0; n4 < 4; ++n4) acc[mt][n4] = mfma32(af[mt], bfr[n4], acc[mt][n4]);
+                for (int n4 = 0; n4 < NT4; ++n4)
+                    acc[mt][n4] = mfma32(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane owns packed column j = lane&31 of each 32x32 tile and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     //      C[m,j] = bf16(gelu(acc + bias[idx]) - cache[idx, m])     (csp_mlp_mm1.cu:354-390)
 #pragma unroll
-    for (int n4 = 0; n4 < 4; ++n4) {
-        const int j = n0 + wn * 128 + n4 * 32 + (lane & 31);
+    for (int n4 = 0; n4 < NT4; ++n4) {
+        const int j = n0 + wn * (BN / 2) + n4 * 32 + (lane & 31);
         const bool live = j < cnt;
         const int col = live ? idxg[j] : 0;
         const float bia = bf16_bits_to_f32(p.bias[col]);
@@ -149,19 +215,33 @@ struct Mm2Params {
     const uint16_t *a, *b;  // a = packed [M,F], b = fc2^T [F,N2]
     uint16_t *c;            // [M,N2], accumulated in place
     const int32_t *indices, *counts;
-    int M, F, N2, NT;
+    int M, F, N2, NT, NR;
 };
 
-__global__ __launch_bounds__(256, 1) void mm2_kernel(const Mm2Params p) {
+template <int BN, int BK, int NST, int WPS>
+__global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
+    using KT = KTile<BK>;
+    constexpr int A_TILE = BM * BK * 2, B_TILE = BK * BN * 2, STAGE = A_TILE + B_TILE;
+    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;
+    constexpr int NT4 = BN / 64;
+    constexpr int BROWB = BN * 2;            // bytes per gathered fc2^T row slice
+    constexpr int BCPR = BN / 8;             // 16-byte chunks per row
+    constexpr int BRPI = 1024 / BROWB;       // rows per DMA instruction (2 for BN=256, 4 for BN=128)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Al = smem;               // [2][A_TILE]  packed activations, k-contiguous
-    unsigned char *Bl = smem + 2 * A_TILE;  // [2][B2_TILE] gathered fc2^T rows [64 k][256 n], row stride 512 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
 
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int g = wid / p.NT, nt = wid - g * p.NT;
+    // all column tiles of fc2^T are live (N2 is dense); the map only reorders them for L2 reuse (see map_tile)
+    const int G = p.M / BM;
+    const int xcdq = (G * p.NT) >> 3, xcdr = (G * p.NT) & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= xcdq + (xcd < xcdr ? 1 : 0)) return;
+    const int t = (xcd < xcdr ? xcd * (xcdq + 1) : xcdr * (xcdq + 1) + (xcd - xcdr) * xcdq) + slot;
+    const int NR = p.NR;
+    const int nb = t / (G * NR), rem = t - nb * (G * NR);
+    const int nr = min(NR, p.NT - nb * NR);
+    const int g = rem / nr, nt = nb * NR + rem - g * nr;
     const int cnt = p.counts[g];
     const int n0 = nt * BN;
     const int ncols = min(BN, p.N2 - n0);  // N2 is a multiple of 8 (checked on the host)
@@ -169,81 +249,104 @@ __global__ __launch_bounds__(256, 1) void mm2_kernel(const Mm2Params p) {
     const int nkb = (cnt + BK - 1) / BK;
     if (nkb == 0) return;
 
-    int aoff[4];
+    int aoff[A_INST];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 8 + (lane >> 3);
-        aoff[i] = (g * BM + row) * p.F + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = KT::lane_row(w * A_INST + i, lane);
+        aoff[i] = (g * BM + row) * p.F + KT::src_chunk_elems(row, lane);
     }
-    // B rows: one DMA instruction = 2 gathered rows of 512 B (32 chunks); stored chunk c of row r <- source chunk c ^ ((r&3)<<2)
-    int keys[8];
+    // The gather keys of a tile are wave-uniform per DMA row, so they are fetched with SCALAR loads (lgkmcnt): the
+    // vector-memory counter then only counts LDS-DMA and the counted vmcnt pipeline below stays intact.  The keys of
+    // the tile issued NEXT iteration are fetched one iteration ahead so their latency hides behind the MFMAs.
+    constexpr int NKEY = B_INST * BRPI;          // keys per wave per tile (16)
+    int keys[NKEY];
     auto load_keys = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = kb * BK + (w * 8 + i) * 2 + (lane >> 5);
-            keys[i] = idxg[k < cnt ? k : 0];
+        for (int j = 0; j < NKEY; ++j) {
+            const int k = kb * BK + w * NKEY + j;
+            keys[j] = idxg[__builtin_amdgcn_readfirstlane(k < cnt ? k : 0)];  // s_load_dword
         }
     };
+    const int rsel = lane / BCPR;                  // which of the instruction's BRPI rows this lane stages
     auto issue = [&](int kb, int buf) {
+        unsigned char *st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(p.a + aoff[i] + kb * BK, Al + buf * A_TILE + (w * 4 + i) * 1024);
+        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BK, st + (w * A_INST + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = (w * 8 + i) * 2 + (lane >> 5);
-            int chunk = (lane & 31) ^ ((r & 3) << 2);
+        for (int i = 0; i < B_INST; ++i) {
+            int key = keys[i * BRPI];
+#pragma unroll
+            for (int rr = 1; rr < BRPI; ++rr) key = rsel == rr ? keys[i * BRPI + rr] : key;
+            const int r = (w * B_INST + i) * BRPI + rsel;
+            int chunk = (lane % BCPR) ^ ((r & 3) << 2);
             chunk = chunk * 8 < ncols ? chunk : 0;  // partial last column tile: stay inside the row
-            glds16(p.b + (int64_t)keys[i] * p.N2 + n0 + chunk * 8, Bl + buf * B2_TILE + (w * 8 + i) * 1024);
+            glds16(p.b + (int64_t)key * p.N2 + n0 + chunk * 8, st + A_TILE + (w * B_INST + i) * 1024);
         }
     };
 
-    f32x16 acc[4][2];  // [n tile][m tile]: MFMA rows = n (fc2^T via transpose reads), MFMA cols = m
+    f32x16 acc[NT4][2];  // [n tile][m tile]: MFMA rows = n (fc2^T via transpose reads), MFMA cols = m
 #pragma unroll
-    for (int n4 = 0; n4 < 4; ++n4)
+    for (int n4 = 0; n4 < NT4; ++n4)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n4][mt][r] = 0.f;
 
-    load_keys(0);
-    issue(0, 0);
-    if (nkb > 1) load_keys(1);
-    const int li = lane & 15, grp = lane >> 4;
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kb + 1 < nkb) {
-            issue(kb + 1, buf ^ 1);
-            if (kb + 2 < nkb) load_keys(kb + 2);
-        }
-        const unsigned char *At = Al + buf * A_TILE;
-        const unsigned char *Bt = Bl + buf * B2_TILE;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 pf[2], wf[4];
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nkb) {
+            load_keys(s);
+            issue(s, s);
+        }
+    if (NST - 1 < nkb) load_keys(NST - 1);
+    const int li = lane & 15, grp = lane >> 4;
+    int buf = 0, nbuf = NST - 1;
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + NST - 1 < nkb) {
+            issue(kb + NST - 1, nbuf);
+            if (kb + NST < nkb) load_keys(kb + NST);
+        }
+        const unsigned char *At = smem + buf * STAGE;
+        const unsigned char *Bt = At + A_TILE;
+        constexpr int KK = BK / 16;
+        bf16x8 pf[2][2], wf[2][NT4];
+        auto load_frags = [&](int kk, int set) {
             const bool kdead = kb * BK + kk * 16 + (lane >> 5) * 8 >= cnt;  // counts are multiples of 8
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 bf16x8 z = {};
-                const bf16x8 v = read_kfrag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
-                pf[mt] = kdead ? z : v;  // packed columns past the count hold garbage
+                const bf16x8 v = KT::frag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
+                pf[set][mt] = kdead ? z : v;  // packed columns past the count hold garbage
             }
 #pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4) {
+            for (int n4 = 0; n4 < NT4; ++n4) {
                 // lane group grp: n half = grp&1, k half = grp>>1; lane li addresses block row li>>2, cols (li&3)*4
                 const int row = kk * 16 + (grp >> 1) * 8 + (li >> 2);
-                const int chunk = (wn * 16 + n4 * 4 + (grp & 1) * 2 + ((li & 3) >> 1)) ^ ((row & 3) << 2);
-                const unsigned char *ba = Bt + row * 512 + chunk * 16 + (li & 1) * 8;
+                const int chunk = (wn * (BN / 16) + n4 * 4 + (grp & 1) * 2 + ((li & 3) >> 1)) ^ ((row & 3) << 2);
+                const unsigned char *ba = Bt + row * BROWB + chunk * 16 + (li & 1) * 8;
                 const s16x4 lo = lds_read_tr16_b64(ba);
-                const s16x4 hi = lds_read_tr16_b64(ba + 4 * 512);
-                wf[n4] = __builtin_bit_cast(
+                const s16x4 hi = lds_read_tr16_b64(ba + 4 * BROWB);
+                wf[set][n4] = __builtin_bit_cast(
                     bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
             }
+        };
+        load_frags(0, 0);
 #pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4)
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[n4][mt] = mfma32(wf[n4], pf[mt], acc[n4][mt]);
+            for (int n4 = 0; n4 < NT4; ++n4)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[n4][mt] = mfma32(wf[kk & 1][n4], pf[kk & 1][mt], acc[n4][mt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane owns row m = lane&31 of each tile and 4 consecutive n per accumulator quad
@@ -253,10 +356,10 @@ __global__ __launch_bounds__(256, 1) void mm2_kernel(const Mm2Params p) {
         const int m = g * BM + wm * 64 + mt * 32 + (lane & 31);
         uint16_t *crow = p.c + (int64_t)m * p.N2;
 #pragma unroll
-        for (int n4 = 0; n4 < 4; ++n4) {
+        for (int n4 = 0; n4 < NT4; ++n4) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const int n = n0 + wn * 128 + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
+                const int n = n0 + wn * (BN / 2) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
                 if (n >= p.N2) continue;
                 const u32x2 old = *(const u32x2 *)(crow + n);
                 const float a0 = round_bf16(acc[n4][mt][q4 * 4 + 0]), a1 = round_bf16(acc[n4][mt][q4 * 4 + 1]);
@@ -332,17 +435,52 @@ int launch_scatter_add(const void *packed, void *unpacked, const int32_t *indice
     return CHIPMUNK_OK;
 }
 
+template <int BN, int BK, int NST, int WPS>
+int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
+    constexpr int LDS = NST * (BM * BK * 2 + BK * BN * 2);
+    auto kern = mm2_kernel<BN, BK, NST, WPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    Mm2Params p = p0;
+    p.NT = (p.N2 + BN - 1) / BN;
+    p.NR = chipmunk_get_option("mm2_nr") > 0 ? chipmunk_get_option("mm2_nr") : 4;
+    if (p.NR > p.NT) p.NR = p.NT;
+    hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, s, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
 int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, const int32_t *counts, int M, int F, int N2,
                hipStream_t s) {
     CM_CHECK(N2 > 0 && N2 % 8 == 0, "mm2: N2 must be a positive multiple of 8 (got %d)", N2);
     CM_CHECK((int64_t)M * F < (1ll << 31), "mm2: M*F too large for 32-bit offsets");
+    Mm2Params p = {(const uint16_t *)a, (const uint16_t *)b, (uint16_t *)c, indices, counts, M, F, N2, 0, 0};
+    switch (chipmunk_get_option("mm2_variant")) {
+        case 1: return launch_mm2_variant<256, 64, 2, 1>(p, s);
+        case 2: return launch_mm2_variant<128, 64, 2, 2>(p, s);
+        case 3: return launch_mm2_variant<128, 64, 3, 1>(p, s);
+        case 5: return launch_mm2_variant<256, 64, 3, 1>(p, s);
+        default: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // measured best on FLUX shapes (profiles/r01_*)
+    }
+}
+
+template <int BN, int BK, int NST, int WPS>
+int launch_mm1_variant(const Mm1Params &p0, hipStream_t s) {
+    constexpr int LDS = NST * (BM * BK * 2 + BN * BK * 2);
+    auto kern = mm1_kernel<BN, BK, NST, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    Mm2Params p = {(const uint16_t *)a, (const uint16_t *)b, (uint16_t *)c, indices, counts, M, F, N2, (N2 + BN - 1) / BN};
-    hipLaunchKernelGGL(mm2_kernel, dim3((M / BM) * p.NT), dim3(256), MLP_LDS, s, p);
+    Mm1Params p = p0;
+    p.NT = (p.F + BN - 1) / BN;
+    p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
+    if (p.NR > p.NT) p.NR = p.NT;
+    hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -353,18 +491,17 @@ extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const
                                     const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream) {
     CM_CHECK(a && b && c && bias && pa_cache, "csp_mlp_mm1: null tensor pointer");
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
-    CM_CHECK(K > 0 && K % BK == 0, "csp_mlp_mm1: K must be a positive multiple of 64 (got %d)", K);
+    CM_CHECK(K > 0 && K % 64 == 0, "csp_mlp_mm1: K must be a positive multiple of 64 (got %d)", K);
     CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31), "csp_mlp_mm1: operand too large for 32-bit offsets");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mm1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
-        attr_set = true;
-    }
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (const uint16_t *)pa_cache,
-                   (uint16_t *)c, indices, counts, M, K, F, (F + BN - 1) / BN};
-    hipLaunchKernelGGL(mm1_kernel, dim3((M / BM) * p.NT), dim3(256), MLP_LDS, (hipStream_t)stream, p);
-    CM_LAUNCH_CHECK();
-    return CHIPMUNK_OK;
+                   (uint16_t *)c, indices, counts, M, K, F, 0, 0};
+    switch (chipmunk_get_option("mm1_variant")) {
+        case 1: return launch_mm1_variant<256, 64, 2, 1>(p, (hipStream_t)stream);
+        case 3: return launch_mm1_variant<128, 64, 3, 1>(p, (hipStream_t)stream);
+        case 4: return launch_mm1_variant<256, 32, 3, 2>(p, (hipStream_t)stream);
+        case 5: return launch_mm1_variant<256, 64, 3, 1>(p, (hipStream_t)stream);
+        default: return launch_mm1_variant<128, 64, 2, 2>(p, (hipStream_t)stream);  // measured best (profiles/r01_*)
+    }
 }
 
 extern "C" int chipmunk_csp_scatter_add(const void *packed, void *unpacked_colmajor, const int32_t *indices,

@@ -143,7 +143,7 @@ class SparseDiffAttn(nn.Module):
                 o_cache = o - ops.csp_attn(q, k, v, inds, counts)
             else:
                 o_cache = o.clone()
-                torch.ops.chipmunk.csp_attn(q, k, v, o_cache, inds, counts, -1)
+                ops.csp_attn_inplace(q, k, v, o_cache, inds, counts, -1)
             self.storage.set_out_cache(o_cache)
             return o
 
@@ -154,7 +154,7 @@ class SparseDiffAttn(nn.Module):
             return o + ops.csp_attn(q, k, v, inds, counts)
         if not self.storage.out_cache.is_offload_enabled:
             o = o.clone()  # the kernel accumulates in place and the cache must survive (reference attn.py:186-188)
-        torch.ops.chipmunk.csp_attn(q, k, v, o, inds, counts, 1)
+        ops.csp_attn_inplace(q, k, v, o, inds, counts, 1)
         return o
 
     def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:

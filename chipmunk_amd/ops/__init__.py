@@ -1,11 +1,11 @@
 """Operator wrappers with the reference's names (``src/chipmunk/ops/__init__.py:1-7``)."""
 from .mlp import run_e2e as mlp
 from .indexed_io import copy_indices, topk_indices, mask_to_indices, scatter_add, packed_mask_to_indices
-from .attn import csp_attn, dense_attn, dense_colsum_attn
+from .attn import csp_attn, csp_attn_inplace, dense_attn, dense_colsum_attn
 from .patch import patchify, unpatchify, patchify_rope
 from .bitpack import bitpack, bitunpack
 from . import voxel
 
 __all__ = ["mlp", "copy_indices", "topk_indices", "mask_to_indices", "scatter_add", "csp_attn", "dense_attn",
            "dense_colsum_attn", "patchify", "unpatchify", "patchify_rope", "bitpack", "bitunpack",
-           "packed_mask_to_indices", "voxel"]
+           "packed_mask_to_indices", "csp_attn_inplace", "voxel"]

@@ -61,4 +61,11 @@ def csp_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, indices: torch.T
                                            indices_counts.contiguous())
 
 
-__all__ = ["csp_attn", "dense_attn", "dense_colsum_attn"]
+def csp_attn_inplace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, indices: torch.Tensor,
+                     indices_counts: torch.Tensor, o_scale: int) -> None:
+    """``o += o_scale * sparse_attention`` in place (the reference's modules call ``torch.ops.chipmunk.csp_attn``
+    directly, ``modules/attn.py:168,189``; this named entry exists so callers can be instrumented)."""
+    torch.ops.chipmunk.csp_attn(q, k, v, o, indices, indices_counts, o_scale)
+
+
+__all__ = ["csp_attn", "csp_attn_inplace", "dense_attn", "dense_colsum_attn"]

@@ -37,6 +37,9 @@ extern "C" {
 const char *chipmunk_last_error(void);
 /* ABI version of this library (bumped on signature changes). */
 int chipmunk_abi_version(void);
+/* Tuning knob: selects a kernel variant ("mm1_variant", "mm2_variant", "attn_variant", ...); 0 = shipped default.
+ * Results are identical across variants; only speed differs.  Used by tools/kbench.py for A/B measurement. */
+int chipmunk_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------- column-sparse attention
  * Replaces chipmunk::csp_attn (reference csrc/attn/csp_attn.cu:315-423; schema csrc/chipmunk.cpp:52).
