@@ -37,6 +37,7 @@ struct AttnParams {
     int cs_stride;
     int B, H, Nq, Nk, G, idx_stride;
     float o_scale;
+    int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the first tile, 2 = gathers only
 };
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -140,120 +141,145 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 *slot = 0.f;
             }
         }
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && p.probe != 1) {
             issue(buf ^ 1);
             if (t + 2 < ntiles) load_keys(t + 2);
         }
+        if (p.probe == 2) continue;
         const unsigned char *Kb = Kl + buf * TILE_BYTES;
         const unsigned char *Vb = Vl + buf * TILE_BYTES;
 
-        // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
-        f32x4 s[3][4];
+        // The 64-key LDS tile is consumed as two 32-key halves (QK^T -> online softmax -> PV per half): the score and
+        // probability registers of only one half are live at a time, which keeps the kernel inside 256 VGPRs with no
+        // scratch (a spill reload is a vector-memory op and would also disturb the LDS-DMA vmcnt accounting).
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) {
+            if (t * KVT + hh * 32 >= valid) break;  // ragged last tile: the second half holds no live key
+            // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = hh*32 + kt*16 + lg*4 + r, q = qb*16 + li)
+            f32x4 s[3][2];
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
+            for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // K fragments run through a 3-deep register ring (two reads in flight ahead of the MFMAs that consume
+            // them; left alone hipcc emits read -> lgkmcnt(0) -> 3 MFMA per fragment and exposes the LDS latency)
+            {
+                auto load_k = [&](int idx) {
+                    const int kt = hh * 2 + (idx >> 2), ks = idx & 3;
+                    const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
+                    return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
+                };
+                bf16x8 kr[3];
+                kr[0] = load_k(0);
+                kr[1] = load_k(1);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+                for (int idx = 0; idx < 8; ++idx) {
+                    if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int kt = idx >> 2, ks = idx & 3;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
-                const bf16x8 a = *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
-#pragma unroll
-                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(a, qf[qb][ks], s[qb][kt]);
-            }
-        }
-        if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
-#pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+                    for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % 3], qf[qb][ks], s[qb][kt]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-        }
+            }
+            if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dead = t * KVT + hh * 32 + kt * 16 + lg * 4 + r >= valid;
+#pragma unroll
+                        for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+                    }
+            }
 
-        // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
-        bf16x8 pb[3][2];
-        float cacc[4][4];
-        if constexpr (COLSUM) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
-        }
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
-            float mx = s[qb][0][0];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m[qb], mx);
-            const float msc = m_new * SCALE_LOG2E;
-            const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
-            m[qb] = m_new;
-            float psum = 0.f;
-            float pv[4][4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
-                    psum += pv[kt][r];
-                }
-            lsum[qb] = lsum[qb] * alpha + psum;
-            if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
-            }
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                bf16x8 pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pk[r] = (__bf16)pv[2 * kp][r];
-                    pk[4 + r] = (__bf16)pv[2 * kp + 1][r];
-                }
-                pb[qb][kp] = pk;
-            }
-            if constexpr (COLSUM) {
-                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
-                const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
-            }
-        }
-        if constexpr (COLSUM) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float tot = row16_sum(cacc[kt][r]);
-                    if (li == 0) atomicAdd(cs_acc + buf * KVT + kt * 16 + lg * 4 + r, tot);
-                }
-        }
-
-        // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                const int row_a = kp * 32 + lg * 4 + (li >> 2);
+            // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
+            auto load_v = [&](int db) {
+                const int row_a = hh * 32 + lg * 4 + (li >> 2);
                 const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
                 const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
                 const s16x4 lo = lds_read_tr16_b64(va);
                 const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
-                const bf16x8 a = __builtin_bit_cast(
+                return __builtin_bit_cast(
                     bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            };
+            bf16x8 vr[3];
+            vr[0] = load_v(0);
+            vr[1] = load_v(1);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
+            bf16x8 pb[3];
+            float cacc[2][4];
+            if constexpr (COLSUM) {
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(a, pb[qb][kp], o[qb][db]);
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
+            }
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                float mx = s[qb][0][0];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+                mx = max_across_rows(mx);
+                const float m_new = fmaxf(m[qb], mx);  // finite: every processed half holds at least one live key
+                const float msc = m_new * SCALE_LOG2E;
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
+                m[qb] = m_new;
+                float psum = 0.f;
+                float pv[2][4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
+                        psum += pv[kt][r];
+                    }
+                lsum[qb] = lsum[qb] * alpha + psum;
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
+                }
+                bf16x8 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pk[r] = (__bf16)pv[0][r];
+                    pk[4 + r] = (__bf16)pv[1][r];
+                }
+                pb[qb] = pk;
+                if constexpr (COLSUM) {
+                    // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
+                    const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
+                }
+            }
+            if constexpr (COLSUM) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float tot = row16_sum(cacc[kt][r]);
+                        if (li == 0) atomicAdd(cs_acc + buf * KVT + hh * 32 + kt * 16 + lg * 4 + r, tot);
+                    }
+            }
+
+            // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
+            {
+#pragma unroll
+                for (int db = 0; db < 8; ++db) {
+                    if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pb[qb], o[qb][db]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -271,8 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
         float l = lsum[qb];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        l = sum_across_rows(l);
         const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
         const int qrow = row0 + qb * 16 + li;
         if (qrow >= p.Nq) continue;
@@ -312,7 +337,9 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     }
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), ATTN_LDS_BYTES, stream, p);
+    AttnParams pp = p;
+    pp.probe = chipmunk_get_option("attn_variant");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), ATTN_LDS_BYTES, stream, pp);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

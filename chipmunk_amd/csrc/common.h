@@ -60,6 +60,33 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with two gfx950 lane-swap VALU ops instead of
+// two ds_bpermute round trips: permlane32_swap(x, x) yields {lo,lo} and {hi,hi}; permlane16_swap pairs rows 0/1, 2/3.
+// The swaps are issued through inline asm: with the builtin, hipcc (ROCm 7.2) folds the two results of
+// __builtin_amdgcn_permlane{16,32}_swap into one when both operands carry the same value and silently drops the
+// reduction (seen in the .s: the fmax of the two results disappears).  Two "+v" operands force two registers; the
+// leading s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see inside the string.
+__device__ __forceinline__ void lane_swap32(float &a, float &b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap16(float &a, float &b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max_across_rows(float x) {
+    float a = x, b = x;
+    lane_swap32(a, b);   // a = {lo, lo}, b = {hi, hi}
+    float c = fmaxf(a, b), d = c;
+    lane_swap16(c, d);   // c = {r0, r0, r2, r2}, d = {r1, r1, r3, r3}
+    return fmaxf(c, d);
+}
+__device__ __forceinline__ float sum_across_rows(float x) {
+    float a = x, b = x;
+    lane_swap32(a, b);
+    float c = a + b, d = c;
+    lane_swap16(c, d);
+    return c + d;
+}
+
 // XCD-aware remap of a 1-D grid (8 XCDs, block b is dispatched to XCD b % 8): returns an id such that every
 // XCD works on a contiguous chunk of the logical index space (L2 affinity only, never correctness).  Bijective.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
