@@ -20,11 +20,15 @@ namespace {
 
 constexpr int QG = 192;   // query rows per group == per workgroup (reference mbm = 192, modules/attn.py:95-96)
 constexpr int QW = 48;    // query rows per wave
-constexpr int KVT = 64;   // gathered keys per LDS tile
+constexpr int KVT = 32;   // gathered keys per LDS tile
+constexpr int NST = 4;    // LDS ring depth: data of 3 tiles in flight ahead of the one being consumed
+constexpr int KRING = 8;  // key ring slots (keys travel NST-1+3 tiles ahead of their use)
 constexpr int HD = 128;   // head dim (reference: "Head dimension must be 128", csp_attn.cu:381-383)
-constexpr int TILE_BYTES = KVT * HD * 2;  // 16 KiB
+constexpr int TILE_BYTES = KVT * HD * 2;  // 8 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;  // csp_128_attn.cu:307
-constexpr int ATTN_LDS_BYTES = 4 * TILE_BYTES + 2 * KVT * 4;
+constexpr int KEY_RING_OFF = 2 * NST * TILE_BYTES;
+constexpr int CS_OFF = KEY_RING_OFF + KRING * 256;
+constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * KVT * 4;
 
 struct AttnParams {
     const uint16_t *q, *k, *v;
@@ -37,19 +41,31 @@ struct AttnParams {
     int cs_stride;
     int B, H, Nq, Nk, G, idx_stride;
     float o_scale;
-    int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the first tile, 2 = gathers only
+    int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Pipeline (per workgroup, t = tile of 32 gathered keys):
+//   iteration t:  wait until tile t has landed (counted vmcnt: the 2 younger tiles stay in flight) -> s_barrier
+//                 -> issue the LDS-DMA of tile t+3 into the slot tile t-1 just vacated (+ wave 0: the gather keys of
+//                 tile t+6 into the key ring) -> QK^T, online softmax, PV on tile t.
+//   The gather keys reach the lanes through LDS as well (global_load_lds_dword by wave 0, ds_read_b32 by everybody):
+//   an ordinary global load of the keys would make hipcc wait vmcnt(0) at its use and drain the DMA pipeline.
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Kl = smem;
-    unsigned char *Vl = smem + 2 * TILE_BYTES;
-    float *cs_acc = (float *)(smem + 4 * TILE_BYTES);  // [2][KVT]
+    unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
+    unsigned char *Vl = smem + NST * TILE_BYTES;   // [NST][TILE_BYTES]
+    int *key_ring = (int *)(smem + KEY_RING_OFF);  // [KRING][64]
+    float *cs_acc = (float *)(smem + CS_OFF);      // [2][KVT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,27 +107,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         if (tid < 2 * KVT) cs_acc[tid] = 0.f;
     }
 
-    int keys[4];
-    auto load_keys = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pos = t * KVT + (w * 4 + i) * 4 + lg;
-            int key = 0;
-            if (pos < valid) {
-                key = GATHER ? idx[pos] : pos;
-                key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);  // memory safety for malformed indices
+    // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
+    auto issue_keys = [&](int T) {
+        if constexpr (GATHER) {
+            if (w == 0) {
+                int pos = T * KVT + lane;
+                pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T % KRING) * 64), 4, 0, 0);
             }
-            keys[i] = key;
         }
     };
-    auto issue = [&](int buf) {
+    // every wave stages rows (2w+i)*4 + lg, i = 0..1, of the K tile and of the V tile: 4 DMA instructions per wave
+    auto issue_data = [&](int T) {
+        const int slot = T % NST;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (w * 4 + i) * 4 + lg;  // row inside the tile
-            const uint16_t *ksrc = kbase + (int64_t)keys[i] * p.ks[2] + ((li ^ (r & 15)) << 3);
-            const uint16_t *vsrc = vbase + (int64_t)keys[i] * p.vs[2] + ((li ^ ((r & 7) << 1)) << 3);
-            glds16(ksrc, Kl + buf * TILE_BYTES + (w * 4 + i) * 1024);
-            glds16(vsrc, Vl + buf * TILE_BYTES + (w * 4 + i) * 1024);
+        for (int i = 0; i < 2; ++i) {
+            const int r = (w * 2 + i) * 4 + lg;  // row inside the tile
+            const int pos = T * KVT + r;
+            int key = 0;
+            if (pos < valid) {
+                key = GATHER ? key_ring[(T % KRING) * 64 + r] : pos;
+                key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);  // memory safety for malformed indices
+            }
+            const uint16_t *ksrc = kbase + (int64_t)key * p.ks[2] + ((li ^ (r & 15)) << 3);
+            const uint16_t *vsrc = vbase + (int64_t)key * p.vs[2] + ((li ^ ((r & 7) << 1)) << 3);
+            glds16(ksrc, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
+            glds16(vsrc, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
         }
     };
 
@@ -123,164 +144,169 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     float m[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lsum[3] = {0.f, 0.f, 0.f};
 
+    // ---- prologue: keys of tiles 0..NST-2 synchronously, then the data of those tiles (+ keys NST-1 .. 2NST-3)
     if (ntiles > 0) {
-        load_keys(0);
-        issue(0);
-        if (ntiles > 1) load_keys(1);
+#pragma unroll
+        for (int T = 0; T < NST - 1; ++T) issue_keys(T);
+        wait_vmcnt<0>();
+        __syncthreads();
+#pragma unroll
+        for (int T = 0; T < NST - 1; ++T) {
+            if (T < ntiles) {
+                issue_data(T);
+                issue_keys(T + NST - 1);
+            }
+        }
     }
 
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const int slot = t % NST;
+        // tile t has landed once at most the NST-2 younger groups (4 DMAs each, +1 key DMA on wave 0) are in flight
+        if (t + NST - 1 <= ntiles) {
+            if (GATHER && w == 0) wait_vmcnt<(NST - 2) * 5>();
+            else wait_vmcnt<(NST - 2) * 4>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
         if constexpr (COLSUM) {
             if (t > 0 && tid < KVT) {
                 const int pos = (t - 1) * KVT + tid;
-                float *slot = cs_acc + ((t - 1) & 1) * KVT + tid;
-                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(*slot);
-                *slot = 0.f;
+                float *acc = cs_acc + ((t - 1) & 1) * KVT + tid;
+                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(*acc);
+                *acc = 0.f;
             }
         }
-        if (t + 1 < ntiles && p.probe != 1) {
-            issue(buf ^ 1);
-            if (t + 2 < ntiles) load_keys(t + 2);
+        if (t + NST - 1 < ntiles && p.probe != 1) {
+            issue_data(t + NST - 1);
+            issue_keys(t + 2 * (NST - 1));
         }
         if (p.probe == 2) continue;
-        const unsigned char *Kb = Kl + buf * TILE_BYTES;
-        const unsigned char *Vb = Vl + buf * TILE_BYTES;
+        const unsigned char *Kb = Kl + slot * TILE_BYTES;
+        const unsigned char *Vb = Vl + slot * TILE_BYTES;
 
-        // The 64-key LDS tile is consumed as two 32-key halves (QK^T -> online softmax -> PV per half): the score and
-        // probability registers of only one half are live at a time, which keeps the kernel inside 256 VGPRs with no
-        // scratch (a spill reload is a vector-memory op and would also disturb the LDS-DMA vmcnt accounting).
-#pragma unroll 1
-        for (int hh = 0; hh < 2; ++hh) {
-            if (t * KVT + hh * 32 >= valid) break;  // ragged last tile: the second half holds no live key
-            // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = hh*32 + kt*16 + lg*4 + r, q = qb*16 + li)
-            f32x4 s[3][2];
+        // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
+        f32x4 s[3][2];
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb)
+        for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // K fragments run through a 3-deep register ring (two reads in flight ahead of the MFMAs that consume
-            // them; left alone hipcc emits read -> lgkmcnt(0) -> 3 MFMA per fragment and exposes the LDS latency)
-            {
-                auto load_k = [&](int idx) {
-                    const int kt = hh * 2 + (idx >> 2), ks = idx & 3;
-                    const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
-                    return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
-                };
-                bf16x8 kr[3];
-                kr[0] = load_k(0);
-                kr[1] = load_k(1);
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {
-                    if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int kt = idx >> 2, ks = idx & 3;
-#pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % 3], qf[qb][ks], s[qb][kt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool dead = t * KVT + hh * 32 + kt * 16 + lg * 4 + r >= valid;
-#pragma unroll
-                        for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
-                    }
-            }
-
-            // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
-            auto load_v = [&](int db) {
-                const int row_a = hh * 32 + lg * 4 + (li >> 2);
-                const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
-                const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
-                const s16x4 lo = lds_read_tr16_b64(va);
-                const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
-                return __builtin_bit_cast(
-                    bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // K fragments run through a 3-deep register ring (two reads in flight ahead of the MFMAs that consume them;
+        // left alone hipcc emits read -> lgkmcnt(0) -> 3 MFMA per fragment and exposes the LDS latency every time)
+        {
+            auto load_k = [&](int idx) {
+                const int kt = idx >> 2, ks = idx & 3;
+                const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
+                return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
             };
-            bf16x8 vr[3];
-            vr[0] = load_v(0);
-            vr[1] = load_v(1);
-            __builtin_amdgcn_sched_barrier(0);
-
-            // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
-            bf16x8 pb[3];
-            float cacc[2][4];
-            if constexpr (COLSUM) {
+            bf16x8 kr[3];
+            kr[0] = load_k(0);
+            kr[1] = load_k(1);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+            for (int idx = 0; idx < 8; ++idx) {
+                if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kt = idx >> 2, ks = idx & 3;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
+                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % 3], qf[qb][ks], s[qb][kt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) {
-                float mx = s[qb][0][0];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
-                mx = max_across_rows(mx);
-                const float m_new = fmaxf(m[qb], mx);  // finite: every processed half holds at least one live key
-                const float msc = m_new * SCALE_LOG2E;
-                const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
-                m[qb] = m_new;
-                float psum = 0.f;
-                float pv[2][4];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
-                        psum += pv[kt][r];
-                    }
-                lsum[qb] = lsum[qb] * alpha + psum;
-                if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                    for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
-                }
-                bf16x8 pk;
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pk[r] = (__bf16)pv[0][r];
-                    pk[4 + r] = (__bf16)pv[1][r];
-                }
-                pb[qb] = pk;
-                if constexpr (COLSUM) {
-                    // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
-                    const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
+                    const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
+                    for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
                 }
+        }
+
+        // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
+        auto load_v = [&](int db) {
+            const int row_a = lg * 4 + (li >> 2);
+            const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
+            const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
+            const s16x4 lo = lds_read_tr16_b64(va);
+            const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
+            return __builtin_bit_cast(
+                bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        };
+        bf16x8 vr[3];
+        vr[0] = load_v(0);
+        vr[1] = load_v(1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
+        bf16x8 pb[3];
+        float cacc[2][4];
+        if constexpr (COLSUM) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+            mx = max_across_rows(mx);
+            const float m_new = fmaxf(m[qb], mx);  // finite: every tile holds at least one live key
+            const float msc = m_new * SCALE_LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
+            m[qb] = m_new;
+            float psum = 0.f;
+            float pv[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
+                    psum += pv[kt][r];
+                }
+            lsum[qb] = lsum[qb] * alpha + psum;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
             }
+            bf16x8 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pk[r] = (__bf16)pv[0][r];
+                pk[4 + r] = (__bf16)pv[1][r];
+            }
+            pb[qb] = pk;
             if constexpr (COLSUM) {
+                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
+                const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float tot = row16_sum(cacc[kt][r]);
-                        if (li == 0) atomicAdd(cs_acc + buf * KVT + hh * 32 + kt * 16 + lg * 4 + r, tot);
-                    }
+                    for (int r = 0; r < 4; ++r) cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
             }
-
-            // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
-            {
+        }
+        if constexpr (COLSUM) {
 #pragma unroll
-                for (int db = 0; db < 8; ++db) {
-                    if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pb[qb], o[qb][db]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 4; ++r) {
+                    const float tot = row16_sum(cacc[kt][r]);
+                    if (li == 0) atomicAdd(cs_acc + (t & 1) * KVT + kt * 16 + lg * 4 + r, tot);
                 }
-            }
+        }
+
+        // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pb[qb], o[qb][db]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -296,8 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     // ---- epilogue: O = O^T / l ; lane holds 4 consecutive d of one query row per (qb, db)
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
-        float l = lsum[qb];
-        l = sum_across_rows(l);
+        const float l = sum_across_rows(lsum[qb]);
         const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
         const int qrow = row0 + qb * 16 + li;
         if (qrow >= p.Nq) continue;
