@@ -86,7 +86,7 @@ struct Mm1Params {
     const uint16_t *a, *b, *bias, *cache;
     uint16_t *c;
     const int32_t *indices, *counts;
-    int M, K, F, NT, NR;
+    int M, K, F, NT, NR, probe;
 };
 
 template <int BN, int BK, int NST, int WPS>
@@ -147,7 +147,12 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
         if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1, nbuf);
+        if (kb + NST - 1 < nkb && p.probe != 1) issue(kb + NST - 1, nbuf);
+        if (p.probe == 2) {
+            buf = buf + 1 == NST ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+            continue;
+        }
         const unsigned char *At = smem + buf * STAGE;
         const unsigned char *Bt = At + A_TILE;
         // operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are in flight while the
@@ -204,6 +209,146 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
                     cp[(int64_t)p.F] = f32_to_bf16_bits(x1);
                     cp[2 * (int64_t)p.F] = f32_to_bf16_bits(x2);
                     cp[3 * (int64_t)p.F] = f32_to_bf16_bits(x3);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mm1, fp8 e4m3
+// BASELINE config C5 (Wan2.1 shapes): the reference's fp8 GEMM1 is a Triton kernel (src/chipmunk/triton/csp_mlp_mm1.py:
+// 37-164): acc = (A_fp8 . B_fp8[idx]) * scale_a * scale_b; x = bf16(gelu(acc + bias)); packed = bf16(x - cache); and it
+// also stores x into the cache (:140), after which the scatter-add of ops/mlp.py:92 adds the delta a second time -- a
+// reference inconsistency.  `update_cache` selects that literal behaviour (1) or the bf16 path's (0: the
+// cache is left to the scatter-add).  Same tile machinery as the bf16 kernel: 128 bytes of K per row and step (BK = 128
+// fp8 elements), v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3fn on gfx950), 8-byte operand fragments.
+struct Mm1Fp8Params {
+    const unsigned char *a, *b;  // fp8 e4m3fn [M,K], [F,K]
+    const uint16_t *bias;
+    uint16_t *cache, *c;
+    const int32_t *indices, *counts;
+    const float *scale_a, *scale_b;
+    int M, K, F, NT, NR, update_cache;
+};
+
+template <int BN, int NST, int WPS>
+__global__ __launch_bounds__(256, WPS) void mm1_fp8_kernel(const Mm1Fp8Params p) {
+    using KT = KTile<64>;  // geometry in BYTES: 128-byte rows, 8 chunks of 16 B
+    constexpr int BKB = 128;
+    constexpr int A_TILE = BM * BKB, B_TILE = BN * BKB, STAGE = A_TILE + B_TILE;
+    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;
+    constexpr int NT4 = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR);
+    if (!tm.live) return;
+    const int g = tm.g, nt = tm.nt;
+    const int cnt = p.counts[g];
+    const int n0 = nt * BN;
+    if (n0 >= cnt) return;
+    const int32_t *idxg = p.indices + (int64_t)g * p.F;
+
+    int aoff[A_INST], boff[B_INST];  // byte offsets
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = KT::lane_row(w * A_INST + i, lane);
+        aoff[i] = (g * BM + row) * p.K + (KT::src_chunk_elems(row, lane) << 1);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const int row = KT::lane_row(w * B_INST + i, lane);
+        const int j = n0 + row;
+        const int key = idxg[j < cnt ? j : n0];
+        boff[i] = key * p.K + (KT::src_chunk_elems(row, lane) << 1);
+    }
+    auto issue = [&](int kb, int buf) {
+        unsigned char *st = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BKB, st + (w * A_INST + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i) glds16(p.b + boff[i] + kb * BKB, st + A_TILE + (w * B_INST + i) * 1024);
+    };
+    // 8 fp8 values (k = 8*(lane>>5) .. +7 of the 16-wide slice kk) of row `row`
+    auto frag = [&](const unsigned char *tile, int row, int kk) {
+        return *(const long *)(tile + row * 128 + ((kk ^ KT::swz(row)) << 4) + ((lane >> 5) << 3));
+    };
+
+    f32x16 acc[2][NT4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n4 = 0; n4 < NT4; ++n4)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][n4][r] = 0.f;
+
+    const int nkb = p.K / BKB;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nkb) issue(s, s);
+    int buf = 0, nbuf = NST - 1;
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + NST - 1 < nkb) issue(kb + NST - 1, nbuf);
+        const unsigned char *At = smem + buf * STAGE;
+        const unsigned char *Bt = At + A_TILE;
+        long af[2][2], bfr[2][NT4];
+        auto load_frags = [&](int kk, int set) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[set][mt] = frag(At, wm * 64 + mt * 32 + (lane & 31), kk);
+#pragma unroll
+            for (int n4 = 0; n4 < NT4; ++n4) bfr[set][n4] = frag(Bt, wn * (BN / 2) + n4 * 32 + (lane & 31), kk);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk + 1 < 8) load_frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int n4 = 0; n4 < NT4; ++n4)
+                    acc[mt][n4] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+
+    const float scale = p.scale_a[0] * p.scale_b[0];
+#pragma unroll
+    for (int n4 = 0; n4 < NT4; ++n4) {
+        const int j = n0 + wn * (BN / 2) + n4 * 32 + (lane & 31);
+        const bool live = j < cnt;
+        const int col = live ? idxg[j] : 0;
+        const float bia = bf16_bits_to_f32(p.bias[col]);
+        uint16_t *crow = p.cache + (int64_t)col * p.M;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int m = g * BM + wm * 64 + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                const u32x2 cv = *(const u32x2 *)(crow + m);
+                float x[4], cc[4] = {__uint_as_float(cv[0] << 16), __uint_as_float(cv[0] & 0xffff0000u),
+                                     __uint_as_float(cv[1] << 16), __uint_as_float(cv[1] & 0xffff0000u)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)  // acc*scale_a*scale_b + bias -> gelu -> bf16 (csp_mlp_mm1.py:121-130)
+                    x[r] = round_bf16(gelu_tanh(acc[mt][n4][q4 * 4 + r] * p.scale_a[0] * p.scale_b[0] + bia));
+                (void)scale;
+                if (live) {
+                    uint16_t *cp = p.c + (int64_t)m * p.F + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cp[(int64_t)r * p.F] = f32_to_bf16_bits(x[r] - cc[r]);  // bf16 subtract (:133)
+                    if (p.update_cache) {
+                        u32x2 nv;
+                        nv[0] = pack_bf16x2(x[0], x[1]);
+                        nv[1] = pack_bf16x2(x[2], x[3]);
+                        *(u32x2 *)(crow + m) = nv;  // reference stores the new activation (:140)
+                    }
                 }
             }
         }
@@ -494,7 +639,7 @@ extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const
     CM_CHECK(K > 0 && K % 64 == 0, "csp_mlp_mm1: K must be a positive multiple of 64 (got %d)", K);
     CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31), "csp_mlp_mm1: operand too large for 32-bit offsets");
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (const uint16_t *)pa_cache,
-                   (uint16_t *)c, indices, counts, M, K, F, 0, 0};
+                   (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe")};
     switch (chipmunk_get_option("mm1_variant")) {
         case 1: return launch_mm1_variant<256, 64, 2, 1>(p, (hipStream_t)stream);
         case 3: return launch_mm1_variant<128, 64, 3, 1>(p, (hipStream_t)stream);
@@ -528,4 +673,27 @@ extern "C" int chipmunk_csp_mlp_mm2_and_scatter_add(const void *packed, void *un
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
     if (int e = launch_scatter_add(packed, unpacked_colmajor, indices, counts, M, F, (hipStream_t)stream)) return e;
     return launch_mm2(mma_a, mma_b, mma_c, indices, counts, M, F, N2, (hipStream_t)stream);
+}
+
+extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, const void *bias, void *pa_cache,
+                                        const int32_t *indices, const int32_t *counts, const float *scale_a,
+                                        const float *scale_b, int M, int K, int F, int update_cache, void *stream) {
+    CM_CHECK(a && b && c && bias && pa_cache && scale_a && scale_b, "csp_mlp_mm1_fp8: null tensor pointer");
+    if (int e = check_mlp_common(M, F, indices, counts)) return e;
+    CM_CHECK(K > 0 && K % 128 == 0, "csp_mlp_mm1_fp8: K must be a positive multiple of 128 (got %d)", K);
+    CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31), "csp_mlp_mm1_fp8: operand too large for 32-bit offsets");
+    constexpr int BN = 128, NST = 2;
+    constexpr int LDS = NST * (BM * 128 + BN * 128);
+    auto kern = mm1_fp8_kernel<BN, NST, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    Mm1Fp8Params p = {(const unsigned char *)a, (const unsigned char *)b, (const uint16_t *)bias, (uint16_t *)pa_cache,
+                      (uint16_t *)c, indices, counts, scale_a, scale_b, M, K, F, (F + BN - 1) / BN, 4, update_cache};
+    if (p.NR > p.NT) p.NR = p.NT;
+    hipLaunchKernelGGL(kern, dim3((((M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, (hipStream_t)stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
 }

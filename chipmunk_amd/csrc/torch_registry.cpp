@@ -164,6 +164,32 @@ void csp_mlp_mm1(at::Tensor a, at::Tensor b_colmajor, at::Tensor c, at::Tensor b
           "csp_mlp_mm1");
 }
 
+// native counterpart of the reference's Triton csp_mlp_mm1_fp8 (src/chipmunk/triton/csp_mlp_mm1.py:143-164)
+void csp_mlp_mm1_fp8(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
+                     at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b,
+                     bool update_cache) {
+    CHECK_DEV(a); CHECK_DEV(b); CHECK_DEV(c); CHECK_DEV(bias); CHECK_DEV(pa_cache_colmajor);
+    CHECK_DEV(indices); CHECK_DEV(indices_counts); CHECK_DEV(scale_a); CHECK_DEV(scale_b);
+    TORCH_CHECK(a.scalar_type() == at::kFloat8_e4m3fn && b.scalar_type() == at::kFloat8_e4m3fn,
+                "a and b must be float8_e4m3fn (OCP; gfx950 has no fnuz)");
+    CHECK_BF16(c); CHECK_BF16(bias); CHECK_BF16(pa_cache_colmajor);
+    CHECK_I32(indices); CHECK_I32(indices_counts);
+    CHECK_CONTIG(a); CHECK_CONTIG(b); CHECK_CONTIG(c); CHECK_CONTIG(bias); CHECK_CONTIG(pa_cache_colmajor);
+    CHECK_CONTIG(indices); CHECK_CONTIG(indices_counts);
+    TORCH_CHECK(scale_a.scalar_type() == at::kFloat && scale_b.scalar_type() == at::kFloat && scale_a.numel() == 1 &&
+                scale_b.numel() == 1, "scale_a and scale_b must be one-element float32 tensors");
+    TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && c.dim() == 2, "a, b, c must be 2D");
+    const int64_t M = a.size(0), K = a.size(1), F = b.size(0);
+    TORCH_CHECK(b.size(1) == K && c.size(0) == M && c.size(1) == F, "shape mismatch");
+    TORCH_CHECK(bias.numel() == F && pa_cache_colmajor.numel() == F * M, "bias must be [F], pa_cache_colmajor [F, M]");
+    c10::DeviceGuard guard(a.device());
+    check(chipmunk_csp_mlp_mm1_fp8(a.data_ptr(), b.data_ptr(), c.data_ptr(), bias.data_ptr(),
+                                   pa_cache_colmajor.data_ptr(), indices.data_ptr<int>(),
+                                   indices_counts.data_ptr<int>(), scale_a.data_ptr<float>(), scale_b.data_ptr<float>(),
+                                   (int)M, (int)K, (int)F, update_cache ? 1 : 0, cur_stream(a)),
+          "csp_mlp_mm1_fp8");
+}
+
 void check_scatter_args(const at::Tensor &packed, const at::Tensor &unpacked, const at::Tensor &inds,
                         const at::Tensor &counts) {
     // reference csrc/indexed_io/scatter_add.cu:111-142 (B is hard-wired to 1, :58-59,138)
@@ -353,6 +379,7 @@ TORCH_LIBRARY(chipmunk, m) {
 
     // additions (not in the reference): native GEMM2 entry, fused packed-mask path, single-kernel bit packing
     m.def("csp_mlp_mm2(Tensor mma_a, Tensor mma_b, Tensor indices, Tensor counts, Tensor(mma_c!) mma_c) -> ()");
+    m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -370,6 +397,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("dense_attn", &dense_attn);
     m.impl("dense_colsum_attn", &dense_colsum_attn);
     m.impl("csp_mlp_mm2", &csp_mlp_mm2);
+    m.impl("csp_mlp_mm1_fp8", &csp_mlp_mm1_fp8);
     m.impl("packed_mask_to_indices", &packed_mask_to_indices);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);

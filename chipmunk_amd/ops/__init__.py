@@ -9,3 +9,5 @@ from . import voxel
 __all__ = ["mlp", "copy_indices", "topk_indices", "mask_to_indices", "scatter_add", "csp_attn", "dense_attn",
            "dense_colsum_attn", "patchify", "unpatchify", "patchify_rope", "bitpack", "bitunpack",
            "packed_mask_to_indices", "csp_attn_inplace", "voxel"]
+
+from . import _fake  # noqa: E402,F401  shape-only ("fake") kernels so torch.compile can trace through the ops

@@ -1,0 +1,48 @@
+"""Shape/dtype-only implementations of the returning ops for FakeTensor / torch.compile tracing.
+
+The reference registers none, so every op is a graph break under ``torch.compile`` ("adding fake impls is
+a free win").  The in-place ops need nothing (they return ``()``)."""
+import torch
+
+
+def _register():
+    lib = torch.library
+
+    @lib.register_fake("chipmunk::csp_128_attn")
+    def _(q, k, v, indices, indices_counts):
+        return torch.empty_like(q)
+
+    @lib.register_fake("chipmunk::dense_attn")
+    def _(q, k, v):
+        return [torch.empty(q.shape, dtype=q.dtype, device=q.device),
+                q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
+
+    @lib.register_fake("chipmunk::dense_colsum_attn")
+    def _(q, k, v, p):
+        groups = (q.shape[2] + 191) // 192
+        return [torch.empty(q.shape, dtype=q.dtype, device=q.device),
+                q.new_empty((q.shape[0], q.shape[1], groups, q.shape[2])),
+                q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
+
+    @lib.register_fake("chipmunk::mask_to_indices")
+    def _(mask, multiple_of, pad_to_multiple_of):
+        b, h, m, n = mask.shape
+        pad_n = (n + pad_to_multiple_of - 1) // pad_to_multiple_of * pad_to_multiple_of
+        return [mask.new_empty((b, h, m, pad_n), dtype=torch.int32), mask.new_empty((b, h, m), dtype=torch.int32)]
+
+    @lib.register_fake("chipmunk::packed_mask_to_indices")
+    def _(packed, shape, multiple_of, pad_to_multiple_of):
+        b, h, m, n = shape
+        pad_n = (n + pad_to_multiple_of - 1) // pad_to_multiple_of * pad_to_multiple_of
+        return [packed.new_empty((b, h, m, pad_n), dtype=torch.int32), packed.new_empty((b, h, m), dtype=torch.int32)]
+
+    @lib.register_fake("chipmunk::bitpack")
+    def _(mask):
+        return mask.new_empty(((mask.numel() + 7) // 8,), dtype=torch.uint8)
+
+    @lib.register_fake("chipmunk::bitunpack")
+    def _(packed, shape):
+        return packed.new_empty(tuple(shape), dtype=torch.bool)
+
+
+_register()

@@ -26,11 +26,28 @@ def mm1(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc
     if fc1w.dtype == torch.bfloat16:
         torch.ops.chipmunk.csp_mlp_mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
     elif fc1w.dtype == torch.float8_e4m3fn:
-        # reference routes to triton csp_mlp_mm1_fp8 (ops/mlp.py:22-23), a path that is broken as shipped
-        # (modules/mlp.py:97 dereferences a list) -- scheduled as a later row, see DESIGN.md
-        raise NotImplementedError("fp8 csp_mlp_mm1 is not built yet on gfx950 (reference path is broken as shipped)")
+        # reference: triton csp_mlp_mm1_fp8(x, fc1w.T, ...) (ops/mlp.py:22-23).  That kernel also stores the new
+        # activation into the cache (triton/csp_mlp_mm1.py:140) and the scatter-add then adds the delta again; here
+        # the cache is left to the scatter-add like on the bf16 path (set FP8_MM1_UPDATES_CACHE for the literal form).
+        csp_mlp_mm1_fp8(x, fc1w, fc1b, indices, counts, sparse_act_T, sparse_act_packed, scale_a, scale_b)
     else:
         raise ValueError(f"Unsupported dtype: {fc1w.dtype}")
+
+
+FP8_MM1_UPDATES_CACHE = False
+
+
+def csp_mlp_mm1_fp8(a: torch.Tensor, b: torch.Tensor, fc1b: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
+                    sparse_act_unpacked_inout: torch.Tensor, sparse_act_packed_out: torch.Tensor,
+                    scale_a: torch.Tensor, scale_b: torch.Tensor) -> None:
+    """Native counterpart of the reference's Triton ``csp_mlp_mm1_fp8`` (same argument order,
+    triton/csp_mlp_mm1.py:143).  ``a`` fp8 ``[M,K]``; ``b`` fp8 ``[F,K]`` (the reference passes ``fc1w.T``, a view of
+    the same storage); scales are the RECIPROCAL quantisation scales (modules/mlp.py:98-99)."""
+    if b.shape[0] == a.shape[1] and b.shape[1] != a.shape[1]:
+        b = b.T  # accept the reference's fc1w.T view
+    torch.ops.chipmunk.csp_mlp_mm1_fp8(a, b.contiguous(), sparse_act_packed_out, fc1b, sparse_act_unpacked_inout,
+                                       indices, counts, scale_a.reshape(1).float(), scale_b.reshape(1).float(),
+                                       FP8_MM1_UPDATES_CACHE)
 
 
 def mm2_fused(packed: torch.Tensor, unpacked_colmajor: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
@@ -79,4 +96,4 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
         mm2_unfused(sparse_act_packed, fc2w_T, cached_out, sparse_act_T, indices, counts, num_sms_scatter_add)
 
 
-__all__ = ["mm1", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2"]
+__all__ = ["mm1", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2", "csp_mlp_mm1_fp8"]

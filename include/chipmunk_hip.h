@@ -82,6 +82,16 @@ int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, cons
 int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const void *bias, const void *pa_cache,
                          const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream);
 
+/* fp8 (OCP e4m3fn) GEMM1 for BASELINE config C5: native counterpart of the reference's Triton csp_mlp_mm1_fp8
+ * (src/chipmunk/triton/csp_mlp_mm1.py:37-164).  a [M,K] fp8, b [F,K] fp8; scale_a / scale_b: device pointers to ONE
+ * fp32 each (the reference passes 0-dim tensors holding the RECIPROCAL quantisation scales, modules/mlp.py:98-99):
+ *   x = bf16(gelu_tanh(a.b[idx] * scale_a * scale_b + bias[idx]));  c[m,j] = bf16(x - pa_cache[idx, m])
+ * update_cache = 1 additionally stores x into pa_cache like the Triton kernel (:140); 0 leaves the cache to the
+ * scatter-add (the bf16 path's contract).  Requires K % 128 == 0. */
+int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, const void *bias, void *pa_cache,
+                             const int32_t *indices, const int32_t *counts, const float *scale_a,
+                             const float *scale_b, int M, int K, int F, int update_cache, void *stream);
+
 /* Replaces chipmunk::csp_mlp_mm2_and_scatter_add (reference csrc/mlp/csp_mlp_mm2_and_scatter_add.cu:96-259 plus the
  * Triton GEMM src/chipmunk/triton/csp_mlp_mm2.py:26-129; schema csrc/chipmunk.cpp:48).
  *  (i)  unpacked_colmajor[idx[g,c], g*128 + r] += packed[g*128 + r, c]           (bf16 add, c < counts[g])

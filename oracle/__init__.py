@@ -125,6 +125,18 @@ def csp_mlp_mm1(a, b_colmajor, c, bias, pa_cache_colmajor, indices, indices_coun
                              _p(_i32(indices_counts)), M, K, F)
 
 
+def csp_mlp_mm1_fp8(a, b, c, bias, pa_cache_colmajor, indices, indices_counts, scale_a, scale_b,
+                    update_cache: bool = False) -> None:
+    """fp8 e4m3fn GEMM1 (reference triton/csp_mlp_mm1.py:37-164); a [M,K], b [F,K] float8_e4m3fn tensors."""
+    M, K = a.shape
+    F = b.shape[0]
+    assert a.dtype == torch.float8_e4m3fn and b.dtype == torch.float8_e4m3fn
+    a8, b8 = a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)
+    lib().oracle_csp_mlp_mm1_fp8(_p(a8), _p(b8), _p(c), _p(bias), _p(pa_cache_colmajor), _p(_i32(indices)),
+                                 _p(_i32(indices_counts)), ctypes.c_float(float(scale_a)), ctypes.c_float(float(scale_b)),
+                                 M, K, F, int(bool(update_cache)))
+
+
 def csp_scatter_add(packed, unpacked_colmajor, sp_inds, sp_counts, num_sms: int = 0) -> None:
     """Accepts the reference's ``[1,M,F]`` / ``[1,F,M]`` shapes (scatter_add.cu:58-59 hard-wires B=1) or 2-D."""
     packed2 = packed[0] if packed.dim() == 3 else packed

@@ -322,6 +322,47 @@ void oracle_csp_mlp_mm2(const uint16_t *packed, const uint16_t *w2t, uint16_t *o
     }
 }
 
+/* OCP fp8 e4m3fn -> float (1-4-3, bias 7, no infinities, S.1111.111 = NaN, max 448) */
+static inline float fp8_e4m3fn_to_f(uint8_t v) {
+    int sign = v >> 7, e = (v >> 3) & 0xf, m = v & 7;
+    float f;
+    if (e == 0xf && m == 7) return NAN;
+    if (e == 0) f = ldexpf((float)m, -9);            /* subnormal: m/8 * 2^-6 */
+    else f = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return sign ? -f : f;
+}
+
+/*
+ * fp8 GEMM1 (src/chipmunk/triton/csp_mlp_mm1.py:37-164):
+ *   acc = (a_fp8 . b_fp8[idx]) * scale_a * scale_b (:121-122);  x = bf16(gelu(acc + bias[idx])) (:124-130);
+ *   c[m,j] = bf16(x - pa_cache[idx, m]) (:133, bf16 subtract);  if update_cache: pa_cache[idx, m] = x (:140).
+ */
+void oracle_csp_mlp_mm1_fp8(const uint8_t *a, const uint8_t *bw, uint16_t *c, const uint16_t *bias, uint16_t *pa_cache,
+                            const int32_t *indices, const int32_t *counts, float scale_a, float scale_b, int M, int K,
+                            int F, int update_cache) {
+    int G = M / 128;
+#pragma omp parallel for schedule(dynamic)
+    for (int m = 0; m < G * 128; ++m) {
+        int g = m / 128;
+        int cnt = counts[g];
+        float *af = (float *)malloc(sizeof(float) * K);
+        for (int kk = 0; kk < K; ++kk) af[kk] = fp8_e4m3fn_to_f(a[(size_t)m * K + kk]);
+        for (int j = 0; j < cnt; ++j) {
+            int col = indices[(size_t)g * F + j];
+            const uint8_t *brow = bw + (size_t)col * K;
+            float acc = 0.f;
+            for (int kk = 0; kk < K; ++kk) acc += af[kk] * fp8_e4m3fn_to_f(brow[kk]);
+            acc = acc * scale_a;
+            acc = acc * scale_b;
+            float x = rbf(gelu_tanh(acc + bf2f(bias[col])));
+            size_t coff = (size_t)col * M + m;
+            c[(size_t)m * F + j] = f2bf(x - bf2f(pa_cache[coff]));
+            if (update_cache) pa_cache[coff] = f2bf(x);
+        }
+        free(af);
+    }
+}
+
 /* dense eager MLP of the reference's CPU path: fc2(gelu_tanh(fc1(x)))  (src/chipmunk/modules/mlp.py:33-34,51-53).
  * x [M,K], w1 [F,K], b1 [F], w2 [N2,F], b2 [N2]; mid/pa/out rounded to bf16 like nn.Linear in bf16. */
 void oracle_dense_mlp(const uint16_t *x, const uint16_t *w1, const uint16_t *b1, const uint16_t *w2,

@@ -73,3 +73,19 @@ def test_gpu_only_ops_fail_loudly_on_cpu_tensors():
             "    print('RAISED', type(e).__name__)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert "RAISED" in out.stdout, out.stdout + out.stderr
+
+
+def test_fake_kernels_give_shapes_without_a_gpu():
+    """torch.compile / FakeTensor tracing: shape-only kernels for the returning ops (chipmunk_amd/ops/_fake.py)."""
+    import chipmunk_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        q = torch.empty(1, 2, 400, 128, dtype=torch.bfloat16)
+        o, l = torch.ops.chipmunk.dense_attn(q, q, q)
+        assert o.shape == q.shape and l.shape == (1, 2, 400, 1) and l.dtype == torch.float32
+        _, cs, _ = torch.ops.chipmunk.dense_colsum_attn(q, q, q, l)
+        assert cs.shape == (1, 2, 3, 400)
+        m = torch.empty(1, 2, 3, 400, dtype=torch.bool)
+        i, c = torch.ops.chipmunk.mask_to_indices(m, 128, 192)
+        assert i.shape == (1, 2, 3, 576) and c.shape == (1, 2, 3) and i.dtype == torch.int32
+        assert torch.ops.chipmunk.bitpack(m).shape == (300,)

@@ -117,3 +117,67 @@ def test_run_e2e_matches_dense_delta(dev):
     ref = act1 @ w2d.T + b2d
     assert_close_bf16(act_T.T, act1, atol=3e-2, what="activation cache after scatter-add")
     assert_close_bf16(out_cache, ref, atol=6e-2, rtol=3e-2, what="sparse step output")
+
+
+@pytest.mark.parametrize("update_cache", [False, True])
+def test_mm1_fp8_vs_oracle(dev, update_cache):
+    """BASELINE config C5: fp8 e4m3fn GEMM1 (reference triton/csp_mlp_mm1.py:37-164), Wan-like K = 1536."""
+    M, K, F = 256, 1536, 1024
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(F, K, generator=g) * 0.05
+    sa, sb = 448.0 / x.abs().max(), 448.0 / w.abs().max()
+    a8, b8 = (x * sa).to(torch.float8_e4m3fn), (w * sb).to(torch.float8_e4m3fn)
+    bias, cache = randn_bf16(F, seed=3, scale=0.2), randn_bf16(F, M, seed=4, scale=0.3)
+    counts = [512, 272]
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    inds = _index_rows(M // 128, F, counts, seed=5)
+    ra, rb = torch.tensor([1.0 / sa]), torch.tensor([1.0 / sb])
+    c_ref, cache_ref = torch.full((M, F), 7.0, dtype=torch.bfloat16), cache.clone()
+    oracle.csp_mlp_mm1_fp8(a8, b8, c_ref, bias, cache_ref, inds, cnt, ra.item(), rb.item(), update_cache)
+    c, cache_d = torch.full((M, F), 7.0, dtype=torch.bfloat16, device=dev), cache.clone().to(dev)
+    torch.ops.chipmunk.csp_mlp_mm1_fp8(a8.to(dev), b8.to(dev), c, bias.to(dev), cache_d, inds.to(dev), cnt.to(dev),
+                                       ra.to(dev), rb.to(dev), update_cache)
+    assert_close_bf16(c, c_ref, what="fp8 mm1 packed")
+    assert_close_bf16(cache_d, cache_ref, what="fp8 mm1 cache")
+    if not update_cache:
+        assert torch.equal(cache_d.cpu().view(torch.int16), cache.view(torch.int16))
+    # sanity against the unquantised math: the fp8 result approximates gelu(x @ w.T + b) - cache
+    ref = torch.nn.functional.gelu(x @ w.T + bias.float(), approximate="tanh") - cache.float().T
+    got = c.float().cpu()
+    for gidx, n in enumerate(counts):
+        rows = slice(gidx * 128, (gidx + 1) * 128)
+        cols = inds[gidx, :n].long()
+        assert (got[rows, :n] - ref[rows][:, cols]).abs().mean() < 0.05
+
+
+def test_sparse_mlp_module_fp8_path(dev, fresh_config):
+    """SparseDiffMlp with an fp8 fc1 (BASELINE C5 shapes scaled down): full step through F8Linear / torch._scaled_mm,
+    sparse step through csp_mlp_mm1_fp8 + scatter-add + GEMM2.  With every column selected the sparse step must track
+    the dense fp8 MLP on the new input."""
+    import chipmunk_amd
+    from chipmunk_amd.modules import SparseDiffMlp, F8Linear
+    from chipmunk_amd.util.layer_counter import LayerCounter
+    cfg = fresh_config
+    cfg["offloading"]["global_disable_offloading"] = True
+    cfg["mlp"].update(dict(top_keys=1.0, random_keys=0.0, full_step_every=4, block_mask_cache=2, first_n_dense_layers=0,
+                           counts_multiple_of=256))
+    torch.manual_seed(0)
+    K, F, M = 1536, 2048, 256
+    fc1 = F8Linear.from_linear(torch.nn.Linear(K, F, device=dev, dtype=torch.bfloat16),
+                               input_float8_dtype=torch.float8_e4m3fn)
+    fc2 = torch.nn.Linear(F, K, device=dev, dtype=torch.bfloat16)
+    act = torch.nn.GELU(approximate="tanh")
+    counter = LayerCounter(1, 1)
+    mlp = SparseDiffMlp(0, counter, fc1, act, fc2, 6)
+    x0 = torch.randn(1, M, K, device=dev, dtype=torch.bfloat16)
+    x1 = x0 + 0.1 * torch.randn_like(x0)
+    with torch.no_grad():
+        try:
+            out0 = mlp(x0)                       # full step (step 0)
+        except (RuntimeError, NotImplementedError) as e:   # torch._scaled_mm support varies with the ROCm build
+            pytest.skip(f"torch._scaled_mm fp8 unavailable here: {e}")
+        out1 = mlp(x1).clone()                   # sparse step (step 1), all columns selected
+        ref1 = fc2(act(fc1(x1)))
+    assert out0.shape == (1, M, K)
+    assert_close_bf16(out1, ref1, atol=8e-2, rtol=5e-2, what="fp8 sparse step vs dense fp8 MLP")

@@ -1,0 +1,91 @@
+"""Pinned-host offload pool on the GPU: D2H on the offload stream, H2D prefetch into the 2-slot device pipeline, the
+compute stream waiting on both (reference util/storage/offloaded_tensor.py:91-178), plus the residency policy."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def cfg(fresh_config):
+    import chipmunk_amd  # noqa: F401
+    assert torch.cuda.is_available()
+    from chipmunk_amd.util.storage import offloaded_tensor as ot
+    ot.gpu_tensors.clear()
+    ot._resident_bytes = 0
+    return fresh_config
+
+
+def test_offload_roundtrip_through_pinned_host(cfg):
+    from chipmunk_amd.util.storage import AttnStorage
+    from chipmunk_amd.util.storage import offloaded_tensor as ot
+    cfg["offloading"]["global_disable_offloading"] = False
+    cfg["offloading"]["attn.out_cache"] = True
+    dev = torch.device("cuda:0")
+    layers = [AttnStorage(i, init_names=["out_cache"]) for i in range(4)]
+    data = [torch.randn(1, 4, 384, 128, device=dev).to(torch.bfloat16) for _ in range(4)]
+    for st, t in zip(layers, data):
+        assert st.out_cache.is_offload_enabled
+        st.set_out_cache(t.clone())
+    for st in layers:
+        assert st.out_cache.cpu_buf[0].is_pinned() and st.out_cache.cpu_buf[0].numel() == data[0].numel()
+    # the model loop: wait(this layer), prefetch(next layer)  (reference hunyuan/models.py:796-801)
+    layers[0].load_async()
+    for i, st in enumerate(layers):
+        st.load_async_wait()
+        if i + 1 < len(layers):
+            layers[i + 1].load_async()
+        got = st.get_out_cache()
+        assert got.device.type == "cuda" and torch.equal(got, data[i])
+        assert got.data_ptr() == ot.gpu_tensors["attn.out_cache"][i % ot.PIPELINE_DEPTH].data_ptr()
+    # only PIPELINE_DEPTH device slots exist for the 4 layers
+    assert len({t.data_ptr() for t in ot.gpu_tensors["attn.out_cache"]}) == ot.PIPELINE_DEPTH
+
+
+def test_offload_cur_value_and_shape_change(cfg):
+    from chipmunk_amd.util.storage import MaybeOffloadedTensor
+    cfg["offloading"]["global_disable_offloading"] = False
+    cfg["offloading"]["mlp.out_cache"] = True
+    dev = torch.device("cuda:0")
+    t = MaybeOffloadedTensor("mlp.out_cache", 0, torch.bfloat16, dev)
+    a = torch.randn(1, 3840, 64, device=dev).to(torch.bfloat16)
+    t.offload(a)
+    t.load_async(); t.load_async_wait()
+    slot = t.get_loaded_value()
+    slot += 1                       # in-place update of the device slot ...
+    t.offload_cur_value()           # ... written back to the host copy
+    b = torch.randn(1, 4352, 64, device=dev).to(torch.bfloat16)   # double -> single block shape switch
+    t2 = MaybeOffloadedTensor("mlp.out_cache", 2, torch.bfloat16, dev)
+    t2.offload(b)
+    t2.load_async(); t2.load_async_wait()
+    assert torch.equal(t2.get_loaded_value(), b)
+    t.load_async(); t.load_async_wait()
+    assert torch.equal(t.get_loaded_value(), a + 1)
+
+
+def test_disabled_offload_keeps_device_tensor(cfg):
+    from chipmunk_amd.util.storage import MlpStorage
+    cfg["offloading"]["global_disable_offloading"] = True
+    st = MlpStorage(0)
+    x = torch.randn(8, 8, device="cuda:0")
+    st.set_indices(x)
+    assert st.get_indices() is x
+    st.load_async(); st.load_async_wait()
+    assert st.get_counts() is None
+
+
+def test_keep_resident_if_fits_policy(cfg):
+    from chipmunk_amd.util.storage import MaybeOffloadedTensor
+    cfg["offloading"].update({"global_disable_offloading": False, "attn.out_cache": True,
+                              "keep_resident_if_fits": True, "hbm_budget_gb": 0.001})  # ~1 MB budget
+    dev = torch.device("cuda:0")
+    small = MaybeOffloadedTensor("attn.out_cache", 0, torch.bfloat16, dev)
+    big = MaybeOffloadedTensor("attn.out_cache", 1, torch.bfloat16, dev)
+    a = torch.randn(256, 128, device=dev).to(torch.bfloat16)          # 64 KB: stays in HBM
+    b = torch.randn(4096, 1024, device=dev).to(torch.bfloat16)        # 8 MB: over budget -> host
+    small.offload(a)
+    big.offload(b)
+    assert small.get_loaded_value() is a and small.cpu_buf[0] is None
+    assert big.cpu_buf[0] is not None and big.cpu_buf[0].is_pinned()
+    big.load_async(); big.load_async_wait()
+    assert torch.equal(big.get_loaded_value(), b)

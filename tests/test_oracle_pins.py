@@ -152,3 +152,44 @@ def test_copy_indices_and_bitpack_roundtrip():
     assert packed.numel() == math.ceil(65 / 8)
     assert torch.equal(oracle.bitunpack(packed, shape), m)
     assert packed[0].item() == sum(int(b) << i for i, b in enumerate(m.flatten()[:8].tolist()))
+
+
+def test_fp8_mm1_oracle_matches_torch_dequant_math():
+    """fp8 GEMM1 restatement vs torch: decode e4m3fn exactly, scale, bias, tanh-GeLU, bf16 round, bf16 subtract."""
+    M, K, F = 128, 256, 256
+    g = torch.Generator().manual_seed(11)
+    a8 = (torch.randn(M, K, generator=g) * 20).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(F, K, generator=g) * 20).to(torch.float8_e4m3fn)
+    bias, cache = randn_bf16(F, seed=1, scale=0.3), randn_bf16(F, M, seed=2)
+    inds = torch.randperm(F, generator=g).int().view(1, F).contiguous()
+    cnt = torch.tensor([F], dtype=torch.int32)
+    c, cache2 = torch.zeros(M, F, dtype=torch.bfloat16), cache.clone()
+    oracle.csp_mlp_mm1_fp8(a8, b8, c, bias, cache2, inds, cnt, 0.01, 0.02, update_cache=True)
+    x = torch.nn.functional.gelu((a8.float() @ b8.float().T) * 0.01 * 0.02 + bias.float(), approximate="tanh")
+    x = x.to(torch.bfloat16)
+    cols = inds[0].long()
+    assert_close_bf16(c, (x[:, cols] - cache.T[:, cols]), what="fp8 packed")
+    assert_close_bf16(cache2.T, x, what="fp8 cache update")       # every column selected -> whole cache rewritten
+
+
+def test_f8linear_scale_arithmetic():
+    """reference modules/mlp_fp8.py:172-195: amax_to_scale / saturating cast / reciprocal scales."""
+    from chipmunk_amd.modules.mlp_fp8 import F8Linear, amax_to_scale, to_fp8_saturated
+    assert amax_to_scale(torch.tensor(2.0), 448.0).item() == 224.0
+    assert amax_to_scale(torch.tensor(0.0), 448.0).item() == 448.0       # clamp(max=max_val) with amax -> 1e-12
+    x = torch.tensor([-1000.0, -1.0, 0.5, 3.0])
+    assert to_fp8_saturated(x, torch.tensor(224.0), 448.0).tolist() == [-448.0, -224.0, 112.0, 448.0]
+    lin = torch.nn.Linear(64, 32).bfloat16()
+    w = lin.weight.data.clone()
+    f8 = F8Linear.from_linear(lin, input_float8_dtype=torch.float8_e4m3fn)
+    assert f8.weight.dtype == torch.float8_e4m3fn and f8.weight_initialized
+    torch.testing.assert_close(f8.scale * f8.scale_reciprocal, torch.tensor(1.0), rtol=1e-6, atol=0)
+    deq = f8.weight.float() * f8.scale_reciprocal
+    assert (deq - w.float()).abs().max() <= w.float().abs().max() / 16 + 1e-6      # 3 mantissa bits
+    xin = torch.randn(4, 64)
+    q1 = f8.quantize_input(xin)
+    assert q1.dtype == torch.float8_e4m3fn and f8.trial_index == 1 and not f8.input_scale_initialized
+    assert torch.isclose(f8.input_scale, 448.0 / xin.abs().max())
+    for _ in range(f8.num_scale_trials):
+        f8.quantize_input(xin * 0.5)
+    assert f8.input_scale_initialized                                   # frozen after the calibration trials
