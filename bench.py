@@ -133,7 +133,9 @@ def build_flux(dev, n_layers, timer):
     mlp_ops = importlib.import_module('chipmunk_amd.ops.mlp')
 
     cfg.reset_to_base()
-    cfg.load_from_file(os.path.join(ROOT, "configs", "flux_c2.yml"))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # stdout carries exactly one JSON line
+        cfg.load_from_file(os.path.join(ROOT, "configs", "flux_c2.yml"))
     # event brackets around the three sparse-step kernels
     mlp_ops.mm1 = timer.wrap("csp_mlp_mm1", mlp_ops.mm1, _mm1_work)
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, _mm2_work)

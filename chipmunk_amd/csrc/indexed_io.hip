@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void mask_to_indices_kernel(const M2IParams p)
 // =====================================================================================  topk_indices
 struct TopkParams {
     const void *act;
+    void *cache;  // DELTA variant: the block-mean cache the activations are compared with and copied into
     int32_t *indices;
     int32_t *counts;
     int rows, cols, multiple_of;
@@ -168,6 +169,15 @@ template <>
 __device__ __forceinline__ float load_as_float<_Float16>(const _Float16 *p, int i) { return (float)p[i]; }
 template <>
 __device__ __forceinline__ float load_as_float<float>(const float *p, int i) { return p[i]; }
+
+template <typename T>
+__device__ __forceinline__ float round_to(float x);
+template <>
+__device__ __forceinline__ float round_to<uint16_t>(float x) { return round_bf16(x); }
+template <>
+__device__ __forceinline__ float round_to<_Float16>(float x) { return (float)(_Float16)x; }
+template <>
+__device__ __forceinline__ float round_to<float>(float x) { return x; }
 
 // counter-based uniform in [0,1): replaces cuRAND Philox of topk_indices.cu:46-49,108 (RNG streams cannot match)
 __device__ __forceinline__ float hash_uniform(uint32_t row, uint32_t col) {
@@ -198,17 +208,28 @@ __device__ __forceinline__ int compact_slot(bool keep, int lane, int w, uint32_t
 // One 1024-thread workgroup per row (the reference's launch shape, topk_indices.cu:200-213).  The quantile of the
 // 1024-column sample is found by rank counting (each thread ranks its own sample against all 1024 through LDS
 // broadcasts) instead of the reference's CUB block merge sort: same element, ~1 us.
-template <typename T>
+// DELTA = true fuses the sparse-MLP sequence |bmfc1 - cache| -> topk_indices -> copy_indices (reference
+// modules/mlp.py:70-85 with bm == mbm): the ranked value is |T(b - cache)| computed on the fly and every selected
+// column (padding included, like copy_indices) is copied into the cache by the thread that owns it.
+template <typename T, bool DELTA>
 __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) {
     __shared__ uint32_t wave_tot[16];
     __shared__ float thr_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x;
     const T *x = (const T *)p.act + (int64_t)row * p.cols;
+    T *xc = DELTA ? (T *)p.cache + (int64_t)row * p.cols : nullptr;
     int32_t *out = p.indices + (int64_t)row * p.cols;
     const int cols = p.cols;
+    auto value = [&](int c) {
+        const float b = load_as_float<T>(x, c);
+        if constexpr (DELTA) return fabsf(round_to<T>(b - load_as_float<T>(xc, c)));
+        else return b;
+    };
 
     if (p.quantile == 0.f) {  // keep everything (topk_indices.cu:51-59)
+        if constexpr (DELTA)
+            for (int c = tid; c < cols; c += 1024) xc[c] = x[c];
         for (int c = tid; c < cols; c += 1024) out[c] = c;
         if (tid == 0) p.counts[row] = cols;
         return;
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
         uint32_t key[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t u = __float_as_uint(load_as_float<T>(x, lane + 64 * j));
+            const uint32_t u = __float_as_uint(value(lane + 64 * j));
             key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned map
         }
         const int k = (int)(1024 * p.quantile);
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int c = pass0 + j * 1024 + tid;
-            v[j] = c < cols ? load_as_float<T>(x, c) : 0.f;
+            v[j] = c < cols ? value(c) : 0.f;
         }
         uint32_t keepbits = 0;
         int before[16];
@@ -290,7 +311,11 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            if (keepbits & (1u << j)) out[base + tot[j * 16 + w] + before[j]] = pass0 + j * 1024 + tid;
+            if (keepbits & (1u << j)) {
+                const int c = pass0 + j * 1024 + tid;
+                out[base + tot[j * 16 + w] + before[j]] = c;
+                if constexpr (DELTA) xc[c] = x[c];
+            }
         base += tot[256];
         __syncthreads();
     }
@@ -302,7 +327,10 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
     if (pad > 0) {
         int pbase = 0;
         const int slot = compact_slot(my_last_invalid != -1, lane, w, wave_tot, pbase);
-        if (slot >= 0 && slot < pad) out[kept + slot] = my_last_invalid;
+        if (slot >= 0 && slot < pad) {
+            out[kept + slot] = my_last_invalid;
+            if constexpr (DELTA) xc[my_last_invalid] = x[my_last_invalid];
+        }
     }
 }
 
@@ -351,6 +379,44 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(const uint8_t *packed, u
     }
 }
 
+// =====================================================================================  2-byte transpose
+// [B, R, C] -> [B, C, R] for 16-bit elements (the column-major activation cache of the sparse MLP is act^T,
+// reference modules/mlp.py:56).  64x64 tiles through LDS: 128-byte row segments on both the read and the write side.
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, uint16_t *dst, int R, int C) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64][72];
+    const int64_t boff = (int64_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = i * 256 + tid, r = item >> 3, ch = item & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c0 + ch * 8 + 8 <= C) v = *(const u32x4 *)(src + boff + (int64_t)(r0 + r) * C + c0 + ch * 8);
+        else if (r0 + r < R)
+            for (int e = 0; e < 8; ++e)
+                if (c0 + ch * 8 + e < C) {
+                    const uint32_t x = src[boff + (int64_t)(r0 + r) * C + c0 + ch * 8 + e];
+                    v[e >> 1] |= x << (16 * (e & 1));
+                }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[ch * 8 + 2 * e][r] = (uint16_t)(v[e] & 0xffffu);
+            tile[ch * 8 + 2 * e + 1][r] = (uint16_t)(v[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = i * 256 + tid, c = item >> 3, ch = item & 7;
+        if (c0 + c >= C) continue;
+        uint16_t *d = dst + boff + (int64_t)(c0 + c) * R + r0 + ch * 8;
+        if (r0 + ch * 8 + 8 <= R && ((R & 7) == 0)) *(u32x4 *)d = *(const u32x4 *)&tile[c][ch * 8];
+        else
+            for (int e = 0; e < 8; ++e)
+                if (r0 + ch * 8 + e < R) d[e] = tile[c][ch * 8 + e];
+    }
+}
+
 size_t m2i_lds_bytes(int n) {
     const int NI = (n + 31) >> 5, NB = (NI + 63) >> 6;
     return (size_t)NB * 64 * 4 + (size_t)32 * NB * 8 + (size_t)32 * NB * 4 + 33 * 4 + 16;
@@ -387,24 +453,44 @@ extern "C" int chipmunk_packed_mask_to_indices(const void *packed, int32_t *indi
     return launch_m2i<true>(packed, indices, counts, rows, n, pad_n, multiple_of, stream);
 }
 
-extern "C" int chipmunk_topk_indices(const void *activation, int dtype, int32_t *indices, int32_t *counts, int rows,
-                                     int cols, double sparsity_amount, int multiple_of, double random_amount,
-                                     void *stream) {
+static int launch_topk(const void *activation, void *cache, int dtype, int32_t *indices, int32_t *counts, int rows,
+                       int cols, double sparsity_amount, int multiple_of, double random_amount, void *stream) {
     CM_CHECK(activation && indices && counts, "topk_indices: null pointer");
     CM_CHECK(rows >= 0 && cols >= 1024, "topk_indices: rows >= 0 and cols >= 1024 required (the quantile is taken over the first 1024 columns); got rows=%d cols=%d", rows, cols);
     CM_CHECK(multiple_of > 0, "topk_indices: multiple_of must be positive");
     CM_CHECK(sparsity_amount >= 0.0 && sparsity_amount <= 1.0, "topk_indices: sparsity_amount must be in [0,1]");
     if (rows == 0) return CHIPMUNK_OK;
-    TopkParams p = {activation, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount};
+    TopkParams p = {activation, cache, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount};
     hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_TOPK(T)                                                                                           \
+    do {                                                                                                         \
+        if (cache) hipLaunchKernelGGL((topk_indices_kernel<T, true>), dim3(rows), dim3(1024), 0, s, p);          \
+        else hipLaunchKernelGGL((topk_indices_kernel<T, false>), dim3(rows), dim3(1024), 0, s, p);               \
+    } while (0)
     switch (dtype) {
-        case CHIPMUNK_DTYPE_BF16: hipLaunchKernelGGL(topk_indices_kernel<uint16_t>, dim3(rows), dim3(1024), 0, s, p); break;
-        case CHIPMUNK_DTYPE_FP16: hipLaunchKernelGGL(topk_indices_kernel<_Float16>, dim3(rows), dim3(1024), 0, s, p); break;
-        case CHIPMUNK_DTYPE_FP32: hipLaunchKernelGGL(topk_indices_kernel<float>, dim3(rows), dim3(1024), 0, s, p); break;
+        case CHIPMUNK_DTYPE_BF16: LAUNCH_TOPK(uint16_t); break;
+        case CHIPMUNK_DTYPE_FP16: LAUNCH_TOPK(_Float16); break;
+        case CHIPMUNK_DTYPE_FP32: LAUNCH_TOPK(float); break;
         default: CM_CHECK(false, "topk_indices: unsupported dtype code %d", dtype);
     }
+#undef LAUNCH_TOPK
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_topk_indices(const void *activation, int dtype, int32_t *indices, int32_t *counts, int rows,
+                                     int cols, double sparsity_amount, int multiple_of, double random_amount,
+                                     void *stream) {
+    return launch_topk(activation, nullptr, dtype, indices, counts, rows, cols, sparsity_amount, multiple_of,
+                       random_amount, stream);
+}
+
+extern "C" int chipmunk_topk_delta_indices(const void *activation, void *cache, int dtype, int32_t *indices,
+                                           int32_t *counts, int rows, int cols, double sparsity_amount,
+                                           int multiple_of, double random_amount, void *stream) {
+    CM_CHECK(cache != nullptr, "topk_delta_indices: cache missing");
+    return launch_topk(activation, cache, dtype, indices, counts, rows, cols, sparsity_amount, multiple_of,
+                       random_amount, stream);
 }
 
 extern "C" int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const int32_t *counts, int B,
@@ -444,6 +530,15 @@ extern "C" int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, voi
     const unsigned grid = (unsigned)((nb + 255) / 256 < 8192 ? (nb + 255) / 256 : 8192);
     hipLaunchKernelGGL(bitunpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)packed,
                        (uint8_t *)mask, n);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_transpose16(const void *src, void *dst, int B, int R, int C, void *stream) {
+    CM_CHECK(src && dst && B > 0 && R > 0 && C > 0, "transpose16: bad arguments");
+    CM_CHECK((C & 7) == 0 || true, "unreachable");
+    hipLaunchKernelGGL(transpose16_kernel, dim3((C + 63) / 64, (R + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, R, C);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

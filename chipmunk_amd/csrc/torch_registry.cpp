@@ -300,6 +300,31 @@ void topk_indices(at::Tensor activation, at::Tensor indices, at::Tensor counts, 
           "topk_indices");
 }
 
+// fused |activation - cache| -> topk_indices -> copy_indices (reference modules/mlp.py:70-85 with bm == mbm)
+void topk_delta_indices(at::Tensor activation, at::Tensor cache, at::Tensor indices, at::Tensor counts,
+                        double sparsity_amount, int64_t multiple_of, double random_amount) {
+    CHECK_DEV(activation); CHECK_DEV(cache); CHECK_DEV(indices); CHECK_DEV(counts);
+    CHECK_CONTIG(activation); CHECK_CONTIG(cache); CHECK_CONTIG(indices); CHECK_CONTIG(counts);
+    TORCH_CHECK(activation.dim() == 3 && cache.sizes() == activation.sizes(), "activation and cache must be [batch, rows, cols]");
+    TORCH_CHECK(cache.scalar_type() == activation.scalar_type(), "activation and cache must have the same dtype");
+    CHECK_I32(indices); CHECK_I32(counts);
+    TORCH_CHECK(indices.sizes() == activation.sizes(), "indices must have the shape of activation");
+    TORCH_CHECK(counts.numel() == activation.size(0) * activation.size(1), "counts must be [batch, rows]");
+    int dtype;
+    switch (activation.scalar_type()) {
+        case at::kBFloat16: dtype = CHIPMUNK_DTYPE_BF16; break;
+        case at::kHalf: dtype = CHIPMUNK_DTYPE_FP16; break;
+        case at::kFloat: dtype = CHIPMUNK_DTYPE_FP32; break;
+        default: TORCH_CHECK(false, "Unsupported dtype for topk_delta_indices");
+    }
+    c10::DeviceGuard guard(activation.device());
+    check(chipmunk_topk_delta_indices(activation.data_ptr(), cache.data_ptr(), dtype, indices.data_ptr<int>(),
+                                      counts.data_ptr<int>(), (int)(activation.size(0) * activation.size(1)),
+                                      (int)activation.size(2), sparsity_amount, (int)multiple_of, random_amount,
+                                      cur_stream(activation)),
+          "topk_delta_indices");
+}
+
 // reference csrc/indexed_io/mask_to_indices.cu:92-143
 std::vector<at::Tensor> mask_to_indices(at::Tensor mask, int64_t multiple_of, int64_t pad_to_multiple_of) {
     TORCH_CHECK(mask.dim() == 4, "mask must be 4-dimensional [b, h, m, n]");
@@ -335,6 +360,20 @@ std::vector<at::Tensor> packed_mask_to_indices(at::Tensor packed, at::IntArrayRe
                                           b * h * m, (int)n, (int)pad_n, (int)multiple_of, cur_stream(packed)),
           "packed_mask_to_indices");
     return {indices, counts};
+}
+
+// x.transpose(-1, -2).contiguous() for 16-bit dtypes in one HBM-rate kernel (reference modules/mlp.py:56)
+at::Tensor transpose_last2(at::Tensor x) {
+    CHECK_DEV(x);
+    TORCH_CHECK(x.dim() >= 2 && x.element_size() == 2, "transpose_last2: need a >=2-D tensor of a 16-bit dtype");
+    x = x.contiguous();
+    const int64_t R = x.size(-2), C = x.size(-1), B = x.numel() / (R * C);
+    auto sizes = x.sizes().vec();
+    std::swap(sizes[sizes.size() - 1], sizes[sizes.size() - 2]);
+    c10::DeviceGuard guard(x.device());
+    at::Tensor out = at::empty(sizes, x.options());
+    check(chipmunk_transpose16(x.data_ptr(), out.data_ptr(), (int)B, (int)R, (int)C, cur_stream(x)), "transpose_last2");
+    return out;
 }
 
 // reference src/chipmunk/ops/bitpack.py:4-69 as single kernels
@@ -380,7 +419,9 @@ TORCH_LIBRARY(chipmunk, m) {
     // additions (not in the reference): native GEMM2 entry, fused packed-mask path, single-kernel bit packing
     m.def("csp_mlp_mm2(Tensor mma_a, Tensor mma_b, Tensor indices, Tensor counts, Tensor(mma_c!) mma_c) -> ()");
     m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
+    m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
+    m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
 }
@@ -398,7 +439,9 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("dense_colsum_attn", &dense_colsum_attn);
     m.impl("csp_mlp_mm2", &csp_mlp_mm2);
     m.impl("csp_mlp_mm1_fp8", &csp_mlp_mm1_fp8);
+    m.impl("topk_delta_indices", &topk_delta_indices);
     m.impl("packed_mask_to_indices", &packed_mask_to_indices);
+    m.impl("transpose_last2", &transpose_last2);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);
 }

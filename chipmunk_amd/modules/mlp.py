@@ -22,6 +22,13 @@ def block_mean(x: torch.Tensor, mbm: int) -> torch.Tensor:
     return x.reshape(b, n // mbm, mbm, c).mean(dim=2)
 
 
+def _transposed(x: torch.Tensor) -> torch.Tensor:
+    """``x.transpose(-1, -2).contiguous()``; one HBM-rate kernel for 16-bit GPU tensors."""
+    if x.is_cuda and x.element_size() == 2:
+        return torch.ops.chipmunk.transpose_last2(x)
+    return x.transpose(-1, -2).contiguous()
+
+
 class SparseDiffMlp:
     def __init__(self, layer_num: int, layer_counter: LayerCounter, fc1: torch.nn.Linear,
                  activation: torch.nn.Module, fc2: torch.nn.Linear, heuristic_sms_scatter_add: int = 6):
@@ -52,7 +59,7 @@ class SparseDiffMlp:
             mid = fc1(x)
             act = self.activation(mid)
             out = fc2(act)
-            self.storage.set_sparse_act_T(act.transpose(-1, -2).contiguous())
+            self.storage.set_sparse_act_T(_transposed(act))
             self.storage.set_out_cache(out)
             self.storage.set_blockmean_mid_cache(block_mean(mid, mbm))
             return out
@@ -62,13 +69,22 @@ class SparseDiffMlp:
         if not reuse_mask:
             bmfc1 = fc1(block_mean(x, mbm))
             r = bm // mbm
-            mdiff = (bmfc1 - self.storage.get_blockmean_mid_cache()).abs()
-            b, rows, f = mdiff.shape
-            mdiff = mdiff.reshape(b, rows // r, r, f).sum(dim=2)
-            inds = torch.empty_like(mdiff, dtype=torch.int32, device=x.device)
-            counts = torch.empty((mdiff.size(0), mdiff.size(1)), dtype=torch.int32, device=x.device)
-            ops.topk_indices(mdiff, inds, counts, 1 - cfg["top_keys"], cfg["counts_multiple_of"], cfg["random_keys"])
-            ops.copy_indices(bmfc1, self.storage.get_blockmean_mid_cache(), inds, counts)
+            cache = self.storage.get_blockmean_mid_cache()
+            if r == 1 and bmfc1.is_cuda and cfg.get("fused_topk_delta", True) and bmfc1.is_contiguous():
+                # one kernel for |bmfc1 - cache| -> top-k indices -> copy of the selected columns into the cache
+                inds = torch.empty_like(bmfc1, dtype=torch.int32)
+                counts = torch.empty((bmfc1.size(0), bmfc1.size(1)), dtype=torch.int32, device=x.device)
+                torch.ops.chipmunk.topk_delta_indices(bmfc1, cache, inds, counts, 1 - cfg["top_keys"],
+                                                      cfg["counts_multiple_of"], cfg["random_keys"])
+            else:
+                mdiff = (bmfc1 - cache).abs()
+                b, rows, f = mdiff.shape
+                mdiff = mdiff.reshape(b, rows // r, r, f).sum(dim=2)
+                inds = torch.empty_like(mdiff, dtype=torch.int32, device=x.device)
+                counts = torch.empty((mdiff.size(0), mdiff.size(1)), dtype=torch.int32, device=x.device)
+                ops.topk_indices(mdiff, inds, counts, 1 - cfg["top_keys"], cfg["counts_multiple_of"],
+                                 cfg["random_keys"])
+                ops.copy_indices(bmfc1, cache, inds, counts)
             self.storage.set_indices(inds)
             self.storage.set_counts(counts)
 

@@ -20,7 +20,8 @@ csp_mlp_mm2_function_ptr = 0  # placeholder for the reference's Triton kernel po
 def mm1(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc1b: torch.Tensor,
         sparse_act_T: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
         scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None) -> None:
-    assert x.dtype == torch.bfloat16
+    # (the reference asserts x is bf16 even on its fp8 branch, one of the reasons that branch cannot run as shipped)
+    assert x.dtype == (torch.float8_e4m3fn if fc1w.dtype == torch.float8_e4m3fn else torch.bfloat16)
     assert sparse_act_packed.dtype == torch.bfloat16
     assert sparse_act_T.dtype == torch.bfloat16
     if fc1w.dtype == torch.bfloat16:
@@ -87,7 +88,7 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
     assert K1 == K1_, "K1 must match"
     K2_, _N = fc2w_T.shape
     assert K2 == K2_, "K2 must match"
-    sparse_act_packed = torch.empty((M, K2), device=x.device, dtype=x.dtype)
+    sparse_act_packed = torch.empty((M, K2), device=x.device, dtype=sparse_act_T.dtype)  # bf16 also when x is fp8
     mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts, mm1_scale_a, mm1_scale_b)
     if USE_FUSED_MLP_MATMUL_2:
         mm2_fused(sparse_act_packed, sparse_act_T, indices, counts, sparse_act_packed, fc2w_T, cached_out,

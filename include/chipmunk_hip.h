@@ -120,6 +120,14 @@ int chipmunk_csp_mlp_mm2(const void *mma_a, const void *mma_b, void *mma_c, cons
 int chipmunk_topk_indices(const void *activation, int dtype, int32_t *indices, int32_t *counts, int rows, int cols,
                           double sparsity_amount, int multiple_of, double random_amount, void *stream);
 
+/* Fused |activation - cache| -> topk_indices -> copy_indices for the sparse-MLP step with bm == mbm (reference
+ * src/chipmunk/modules/mlp.py:70-85): ranks the element-wise |delta| (rounded to the tensor dtype like the eager ops),
+ * writes indices / counts exactly like chipmunk_topk_indices on that delta, and copies every selected column of
+ * `activation` into `cache`.  One kernel instead of abs + sum + topk_indices + copy_indices. */
+int chipmunk_topk_delta_indices(const void *activation, void *cache, int dtype, int32_t *indices, int32_t *counts,
+                                int rows, int cols, double sparsity_amount, int multiple_of, double random_amount,
+                                void *stream);
+
 /* Replaces chipmunk::mask_to_indices (reference csrc/indexed_io/mask_to_indices.cu:92-143; schema chipmunk.cpp:60).
  * mask [rows, n] bool bytes; indices [rows, pad_n] int32; counts [rows] int32.  Bit-exact order: True columns of
  * residue class t (mod 32) ascending for t = 0..31, then the first False columns ascending up to multiple_of. */
@@ -135,6 +143,10 @@ int chipmunk_packed_mask_to_indices(const void *packed, int32_t *indices, int32_
  * dst[b,row,idx] = src[b,row,idx] for the first counts[b,row/R] entries of inds[b,row/R,:]; elem_size 2 or 4. */
 int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const int32_t *counts, int B, int M, int R,
                           int F, int elem_size, void *stream);
+
+/* [B,R,C] -> [B,C,R] for 16-bit elements: builds the column-major activation cache `pa.transpose(-1,-2).contiguous()`
+ * of the sparse MLP's full step (reference src/chipmunk/modules/mlp.py:56) at HBM rate. */
+int chipmunk_transpose16(const void *src, void *dst, int B, int R, int C, void *stream);
 
 /* bitpack / bitunpack (reference src/chipmunk/ops/bitpack.py:4-69): 8 bools -> 1 byte, little-endian, flat. */
 int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream);

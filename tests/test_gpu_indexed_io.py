@@ -104,3 +104,37 @@ def test_copy_indices(dev, dtype):
     out = dst.clone().to(dev)
     torch.ops.chipmunk.copy_indices(src.to(dev), out, inds.to(dev), counts.to(dev))
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("sparsity,multiple_of,rk", [(0.7, 256, 0.0), (0.85, 112, 0.0), (0.7, 256, 0.05)])
+def test_topk_delta_indices_equals_unfused_sequence(dev, sparsity, multiple_of, rk):
+    """fused |b - cache| -> topk_indices -> copy_indices == the three separate ops (reference modules/mlp.py:70-85)."""
+    B, R, C = 1, 6, 12288
+    g = torch.Generator().manual_seed(23)
+    b = torch.randn(B, R, C, generator=g).to(torch.bfloat16).to(dev)
+    cache0 = (b.float().cpu() + 0.3 * torch.randn(B, R, C, generator=g)).to(torch.bfloat16).to(dev)
+    # unfused
+    mdiff = (b - cache0).abs()
+    i1 = torch.full((B, R, C), -9, dtype=torch.int32, device=dev)
+    c1 = torch.zeros(B, R, dtype=torch.int32, device=dev)
+    cache1 = cache0.clone()
+    torch.ops.chipmunk.topk_indices(mdiff, i1, c1, sparsity, multiple_of, rk)
+    torch.ops.chipmunk.copy_indices(b, cache1, i1, c1)
+    # fused
+    i2 = torch.full((B, R, C), -9, dtype=torch.int32, device=dev)
+    c2 = torch.zeros(B, R, dtype=torch.int32, device=dev)
+    cache2 = cache0.clone()
+    torch.ops.chipmunk.topk_delta_indices(b, cache2, i2, c2, sparsity, multiple_of, rk)
+    assert torch.equal(c1, c2) and torch.equal(i1, i2)
+    assert torch.equal(cache1.view(torch.int16), cache2.view(torch.int16))
+    if rk == 0.0:   # and against the oracle on the eager |delta|
+        ri = torch.full((B, R, C), -9, dtype=torch.int32)
+        rc = torch.zeros(B, R, dtype=torch.int32)
+        oracle.topk_indices(mdiff.cpu(), ri, rc, sparsity, multiple_of, 0.0)
+        assert torch.equal(i2.cpu(), ri) and torch.equal(c2.cpu(), rc)
+
+
+@pytest.mark.parametrize("shape", [(1, 3840, 12288), (2, 100, 72), (1, 4352, 1024)])
+def test_transpose_last2(dev, shape):
+    x = torch.randn(*shape).to(torch.bfloat16).to(dev)
+    assert torch.equal(torch.ops.chipmunk.transpose_last2(x), x.transpose(-1, -2).contiguous())
