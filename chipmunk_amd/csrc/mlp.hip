@@ -608,6 +608,10 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
         case 2: return launch_mm2_variant<128, 64, 2, 2>(p, s);
         case 3: return launch_mm2_variant<128, 64, 3, 1>(p, s);
         case 5: return launch_mm2_variant<256, 64, 3, 1>(p, s);
+        case 6: return launch_mm2_variant<128, 32, 4, 2>(p, s);
+        case 7: return launch_mm2_variant<128, 32, 3, 3>(p, s);
+        case 8: return launch_mm2_variant<256, 32, 3, 3>(p, s);
+        case 9: return launch_mm2_variant<256, 64, 2, 2>(p, s);
         default: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // measured best on FLUX shapes (profiles/r01_*)
     }
 }
@@ -645,6 +649,10 @@ extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const
         case 3: return launch_mm1_variant<128, 64, 3, 1>(p, (hipStream_t)stream);
         case 4: return launch_mm1_variant<256, 32, 3, 2>(p, (hipStream_t)stream);
         case 5: return launch_mm1_variant<256, 64, 3, 1>(p, (hipStream_t)stream);
+        case 6: return launch_mm1_variant<128, 32, 4, 2>(p, (hipStream_t)stream);
+        case 7: return launch_mm1_variant<128, 32, 3, 3>(p, (hipStream_t)stream);
+        case 8: return launch_mm1_variant<128, 64, 2, 3>(p, (hipStream_t)stream);
+        case 9: return launch_mm1_variant<128, 64, 2, 4>(p, (hipStream_t)stream);
         default: return launch_mm1_variant<128, 64, 2, 2>(p, (hipStream_t)stream);  // measured best (profiles/r01_*)
     }
 }

@@ -1,0 +1,159 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle is too slow there), plus the
+domain's edge cases: empty / ragged groups, duplicate (colliding) indices, all-true / all-false mask rows."""
+import math
+
+import pytest
+import torch
+
+import oracle
+from helpers import assert_close_bf16, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import chipmunk_amd  # noqa: F401
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_c3_sparse_attention_with_all_keys_equals_dense(dev):
+    """HunyuanVideo C3 sequence (119 056 tokens), 1 head: identity index lists (every key kept) must reproduce the
+    dense kernel, and the dense kernel must agree with SDPA on a slice of query rows."""
+    N, H = 119056, 1
+    g = torch.Generator(device=dev).manual_seed(1)
+    q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
+    G = math.ceil(N / 192)
+    o_dense, l = torch.ops.chipmunk.dense_attn(q, k, v)
+    # identity indices for a subset of groups only (the full index tensor would be 119056*621*4 B = 296 MB: fine)
+    inds = torch.arange(N, dtype=torch.int32, device=dev).expand(1, H, G, N).contiguous()
+    counts = torch.full((1, H, G), N, dtype=torch.int32, device=dev)
+    o_sparse = torch.zeros_like(q)
+    torch.ops.chipmunk.csp_attn(q, k, v, o_sparse, inds, counts, 1)
+    assert_close_bf16(o_sparse, o_dense, atol=1e-2, rtol=1e-2, what="C3 identity sparse vs dense")
+    rows = slice(50000, 50384)
+    ref = torch.nn.functional.scaled_dot_product_attention(q[:, :, rows].float(), k.float(), v.float())
+    assert_close_bf16(o_dense[:, :, rows], ref, atol=1e-2, rtol=2e-2, what="C3 dense vs SDPA slice")
+    lref = 1.0 / torch.exp((q[:, :, rows].float() @ k.float().transpose(-1, -2)) / math.sqrt(128)).sum(-1, keepdim=True)
+    torch.testing.assert_close(l[:, :, rows], lref, rtol=2e-3, atol=0)
+
+
+def test_c3_cache_plus_delta_identity(dev):
+    """The identity the method rests on, at C3 size: o_cache = dense - sparse; o_cache + sparse == dense."""
+    N, H, count = 119056, 1, 7296
+    g = torch.Generator(device=dev).manual_seed(2)
+    q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
+    G = math.ceil(N / 192)
+    inds = torch.zeros(1, H, G, G * 192, dtype=torch.int32, device=dev)
+    for g0 in range(0, G, 64):
+        r = torch.rand(min(64, G - g0), N, device=dev, generator=g)
+        inds[0, 0, g0:g0 + r.shape[0], :count] = r.topk(count, dim=-1).indices.to(torch.int32)
+    counts = torch.full((1, H, G), count, dtype=torch.int32, device=dev)
+    import chipmunk_amd
+    o, _ = chipmunk_amd.ops.dense_attn(q, k, v)
+    sparse = chipmunk_amd.ops.csp_attn(q, k, v, inds, counts)
+    assert sparse.shape == q.shape
+    back = (o - sparse) + sparse
+    assert_close_bf16(back, o, atol=2e-2, rtol=2e-2, what="C3 cache + delta")
+    # the sparse result is a convex combination of the selected V rows: bounded by their extrema per group
+    sel = v[0, 0, inds[0, 0, 5, :count].long()].float()
+    grp = sparse[0, 0, 5 * 192:6 * 192].float()
+    assert (grp <= sel.max(0).values + 2e-2).all() and (grp >= sel.min(0).values - 2e-2).all()
+
+
+def test_c3_mask_to_indices_properties_and_fused_path(dev):
+    """C3 mask shape (2 of 24 heads): counts = popcount rounded up to 128; per row the index list is the reference's
+    class-interleaved order (strictly increasing inside each residue class mod 32, classes ascending); the fused
+    packed-bits path returns identical tensors."""
+    import chipmunk_amd
+    H, G, N = 2, 621, 119232
+    g = torch.Generator(device=dev).manual_seed(3)
+    mask = torch.rand(1, H, G, N, device=dev, generator=g) < 0.06
+    inds, counts = torch.ops.chipmunk.mask_to_indices(mask, 128, 192)
+    pop = mask.sum(-1).to(torch.int32)
+    assert torch.equal(counts, ((pop + 127) // 128) * 128)
+    row_i = inds[0, 1, 300, :pop[0, 1, 300]].cpu()
+    cls = row_i % 32
+    assert (cls[1:] >= cls[:-1]).all()
+    same = cls[1:] == cls[:-1]
+    assert (row_i[1:][same] > row_i[:-1][same]).all()
+    assert torch.equal(torch.sort(row_i).values, torch.nonzero(mask[0, 1, 300]).flatten().cpu().to(torch.int32))
+    pad = inds[0, 1, 300, pop[0, 1, 300]:counts[0, 1, 300]].cpu()
+    assert torch.equal(pad, torch.nonzero(~mask[0, 1, 300]).flatten()[:pad.numel()].cpu().to(torch.int32))
+    packed, shp = chipmunk_amd.ops.bitpack(mask)
+    i2, c2 = chipmunk_amd.ops.packed_mask_to_indices(packed, shp, 128, 192)
+    assert torch.equal(c2, counts)
+    live = torch.arange(inds.shape[-1], device=dev)[None, None, None, :] < counts[..., None]
+    assert torch.equal(i2[live], inds[live])
+
+
+def test_c2_mlp_full_size_linearity(dev):
+    """FLUX C2 MLP shape (M 4352, K 3072, F 12288): GEMM2 is linear in the packed activations and in-place additive:
+    mm2(2*p) - C0 == 2 * (mm2(p) - C0) up to bf16 rounding; scatter-add twice == adding 2*p once."""
+    M, K, F, keep = 4352, 3072, 12288, 4096
+    g = torch.Generator(device=dev).manual_seed(4)
+    packed = (torch.randn(M, F, device=dev, generator=g) * 0.125).to(torch.bfloat16)
+    w2t = (torch.randn(F, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    inds = torch.stack([torch.randperm(F, device=dev, generator=g) for _ in range(M // 128)]).to(torch.int32)
+    counts = torch.full((M // 128,), keep, dtype=torch.int32, device=dev)
+    c1, c2 = torch.zeros(M, K, device=dev, dtype=torch.bfloat16), torch.zeros(M, K, device=dev, dtype=torch.bfloat16)
+    torch.ops.chipmunk.csp_mlp_mm2(packed, w2t, inds, counts, c1)
+    torch.ops.chipmunk.csp_mlp_mm2(packed * 2, w2t, inds, counts, c2)
+    assert_close_bf16(c2, c1.float() * 2, atol=2e-2, rtol=2e-2, what="mm2 linearity")
+    rows = slice(128 * 7, 128 * 8)
+    ref = packed[rows, :keep].float() @ w2t[inds[7, :keep].long()].float()
+    assert_close_bf16(c1[rows], ref, atol=3e-2, rtol=2e-2, what="mm2 group 7 vs torch")
+    cache = torch.zeros(F, M, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        torch.ops.chipmunk.csp_scatter_add(packed[None], cache[None], inds[None], counts[None], 6)
+    once = torch.zeros(F, M, device=dev, dtype=torch.bfloat16)
+    torch.ops.chipmunk.csp_scatter_add((packed * 2)[None], once[None], inds[None], counts[None], 6)
+    assert torch.equal(cache, once)          # x + x == 2x exactly in bf16
+    assert cache[inds[3, keep:].long(), 3 * 128:4 * 128].abs().sum() == 0   # unselected columns untouched
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_empty_and_ragged_groups(dev):
+    n, H = 576, 2
+    q, k, v = [randn_bf16(1, H, n, 128, seed=s) for s in (1, 2, 3)]
+    inds = torch.stack([torch.randperm(n, generator=torch.Generator().manual_seed(i)) for i in range(H * 3)])
+    inds = inds.view(1, H, 3, n).to(torch.int32)
+    counts = torch.tensor([[[0, 16, 576], [48, 0, 32]]], dtype=torch.int32)   # empty groups, tiny, everything
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what="ragged counts")
+    assert (o[0, 0, :192] == 0).all() and (o[0, 1, 192:384] == 0).all()       # empty group -> zeros (documented)
+    o0 = randn_bf16(1, H, n, 128, seed=9)
+    oi = o0.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), oi, inds.to(dev), counts.to(dev), -1)
+    assert torch.equal(oi[0, 0, :192].cpu(), o0[0, 0, :192])                   # in place: empty group leaves o alone
+
+
+def test_duplicate_indices_are_not_deduplicated(dev):
+    """Collisions: the reference gathers whatever the list says: a key listed twice counts twice."""
+    n, H, count = 384, 1, 64
+    q, k, v = [randn_bf16(1, H, n, 128, seed=s) for s in (4, 5, 6)]
+    base = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:32]
+    inds = torch.zeros(1, H, 2, n, dtype=torch.int32)
+    inds[0, 0, :, :count] = torch.cat([base, base]).to(torch.int32)          # every key twice
+    counts = torch.full((1, H, 2), count, dtype=torch.int32)
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what="duplicates vs oracle")
+    inds1 = inds.clone(); inds1[0, 0, :, 32:] = 0
+    o_single = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds1.to(dev),
+                                              torch.full((1, H, 2), 32, dtype=torch.int32, device=dev))
+    assert_close_bf16(o, o_single, what="softmax is invariant to duplicating every key")
+
+
+def test_mask_rows_all_true_all_false_and_tiny(dev):
+    n = 200   # not a multiple of 32, 64 or 192
+    mask = torch.zeros(1, 1, 3, n, dtype=torch.bool)
+    mask[0, 0, 0] = True
+    mask[0, 0, 2, [0, 199]] = True
+    ref_i, ref_c = oracle.mask_to_indices(mask, 128, 192)
+    i, c = torch.ops.chipmunk.mask_to_indices(mask.to(dev), 128, 192)
+    assert torch.equal(c.cpu(), ref_c) and c.cpu().tolist() == [[[256, 0, 128]]]
+    assert torch.equal(i[0, 0, 0, :200].cpu(), ref_i[0, 0, 0, :200])           # all True: 200 written, count 256
+    assert torch.equal(i[0, 0, 2, :128].cpu(), ref_i[0, 0, 2, :128])
