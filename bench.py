@@ -186,6 +186,22 @@ def build_flux(dev, n_layers, timer):
     return step, dense_step, desc
 
 
+def pmc_traffic(op_name):
+    """HBM bytes per launch of the op's kernels from the committed PMC run (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kbench.py at the C2 single-block shape, FETCH_SIZE doubled
+    per MI355X_MICROARCH.md).  bench.py cannot collect counters itself; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"]}
+    keys = parts.get(op_name, [])
+    if not keys or any(k not in t for k in keys):
+        return None
+    return sum(t[k]["hbm_bytes_per_launch"] for k in keys)
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(n_layers):
     """Reference dense CPU path restated by the oracle (kind 'port'), on a bounded sample of the same workload:
@@ -257,7 +273,7 @@ def main():
         elapsed = float(tmax.item())
 
     dense_sps = None
-    if args.dense_steps > 0 and rank == 0:
+    if args.dense_steps > 0 and rank == 0 and world == 1:
         dense_step(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -269,6 +285,7 @@ def main():
     if rank != 0:
         return
     value = world * args.steps / elapsed
+    desc["parallelism"] = f"independent replicas x{world} (no data-path collective)"
     kernels = timer.summary()
     roof = None
     if kernels:
@@ -276,7 +293,7 @@ def main():
         ms, flops, byts = timer.probe(name)
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFS, "traffic": None, "avg_launch_ms": ms,
+                "frac": achieved / MFMA_BF16_PEAK_TFS, "traffic": pmc_traffic(name), "avg_launch_ms": ms,
                 "in_region_avg_ms_incl_launch_gaps": k["avg_ms"], "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts}
     line = {
@@ -289,8 +306,8 @@ def main():
                         "tflops": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 1)} for n, k in kernels.items()},
         "dense_gpu_comparator": None if dense_sps is None else {
             "value": dense_sps, "unit": "steps/s", "what": "same loop, F.scaled_dot_product_attention + nn.Linear (rocBLAS/hipBLASLt)",
-            "sparse_over_dense": value / world / dense_sps},
-        "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.layers),
+            "sparse_over_dense": value / dense_sps},
+        "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.layers),
     }
     print(json.dumps(line))
 

@@ -36,6 +36,8 @@ struct AttnParams {
     int64_t qs[3], ks[3], vs[3], os[3];
     const int32_t *indices, *counts;
     float *l_out;
+    float *m_out;       // optional: final running max per query row (scratch for the column-sum pass)
+    const float *m_in;  // CSONLY: that max, read back
     const float *p_in;
     uint16_t *cs;
     int cs_stride;
@@ -59,13 +61,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                 tile t+6 into the key ring) -> QK^T, online softmax, PV on tile t.
 //   The gather keys reach the lanes through LDS as well (global_load_lds_dword by wave 0, ds_read_b32 by everybody):
 //   an ordinary global load of the keys would make hipcc wait vmcnt(0) at its use and drain the DMA pipeline.
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+// CSONLY = second pass of dense_colsum_attn: only K is staged, S^T is recomputed against the FINAL row max from the
+// first pass and reduced to the 192-row column sums; no softmax state, no V, no O accumulators (so it runs at twice the
+// occupancy).  exp2(s - m)*exp2(m) does not depend on which m centres it, only the bf16 rounding points move.
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
+__global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KEYOFF = (CSONLY ? 1 : 2) * NST * TILE_BYTES;  // the column-sum pass has no V ring
     unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
     unsigned char *Vl = smem + NST * TILE_BYTES;   // [NST][TILE_BYTES]
-    int *key_ring = (int *)(smem + KEY_RING_OFF);  // [KRING][64]
-    float *cs_acc = (float *)(smem + CS_OFF);      // [2][KVT]
+    int *key_ring = (int *)(smem + KEYOFF);        // [KRING][64]
+    float *cs_acc = (float *)(smem + KEYOFF + KRING * 256);  // [2][KVT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,11 +104,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 
     float prevl[3] = {0.f, 0.f, 0.f};
-    if constexpr (COLSUM) {
+    float cs_msc[3] = {0.f, 0.f, 0.f}, cs_rowfac[3] = {0.f, 0.f, 0.f};  // CSONLY: per-row constants
+    if constexpr (COLSUM || CSONLY) {
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
             const int qrow = row0 + qb * 16 + li;
             prevl[qb] = qrow < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qrow] : 0.f;
+            if constexpr (CSONLY) {
+                cs_msc[qb] = (qrow < p.Nq ? p.m_in[(int64_t)bh * p.Nq + qrow] : 0.f) * SCALE_LOG2E;
+                // bf16(exp2(m*c) * prev_l)  (dense_colsum_attn.cu:268-271), with the final max
+                cs_rowfac[qb] = round_bf16(__builtin_amdgcn_exp2f(cs_msc[qb]) * prevl[qb]);
+            }
         }
         if (tid < 2 * KVT) cs_acc[tid] = 0.f;
     }
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             const uint16_t *ksrc = kbase + (int64_t)key * p.ks[2] + ((li ^ (r & 15)) << 3);
             const uint16_t *vsrc = vbase + (int64_t)key * p.vs[2] + ((li ^ ((r & 7) << 1)) << 3);
             glds16(ksrc, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
-            glds16(vsrc, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
+            if constexpr (!CSONLY) glds16(vsrc, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
         }
     };
 
@@ -163,13 +175,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         const int slot = t % NST;
         // tile t has landed once at most the NST-2 younger groups (4 DMAs each, +1 key DMA on wave 0) are in flight
         if (t + NST - 1 <= ntiles) {
-            if (GATHER && w == 0) wait_vmcnt<(NST - 2) * 5>();
-            else wait_vmcnt<(NST - 2) * 4>();
+            constexpr int L = CSONLY ? 2 : 4;  // DMA instructions per wave per tile
+            if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
+            else wait_vmcnt<(NST - 2) * L>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if constexpr (COLSUM) {
+        if constexpr (COLSUM || CSONLY) {
             if (t > 0 && tid < KVT) {
                 const int pos = (t - 1) * KVT + tid;
                 float *acc = cs_acc + ((t - 1) & 1) * KVT + tid;
@@ -199,16 +212,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
                 return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
             };
-            bf16x8 kr[3];
-            kr[0] = load_k(0);
-            kr[1] = load_k(1);
+            constexpr int FR = COLSUM ? 2 : 3;  // the column-sum variant is register-bound: 1 read ahead instead of 2
+            bf16x8 kr[FR];
+#pragma unroll
+            for (int i = 0; i < FR - 1; ++i) kr[i] = load_k(i);
 #pragma unroll
             for (int idx = 0; idx < 8; ++idx) {
-                if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
+                if (idx + FR - 1 < 8) kr[(idx + FR - 1) % FR] = load_k(idx + FR - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const int kt = idx >> 2, ks = idx & 3;
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % 3], qf[qb][ks], s[qb][kt]);
+                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -223,6 +237,30 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 }
         }
 
+        if constexpr (CSONLY) {
+            float cacc[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -cs_msc[qb]));
+                        cacc[kt][r] += round_bf16_fast(round_bf16_fast(pe) * cs_rowfac[qb]);
+                    }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tot = row16_sum(cacc[kt][r]);
+                    if (li == 0) atomicAdd(cs_acc + (t & 1) * KVT + kt * 16 + lg * 4 + r, tot);
+                }
+            continue;
+        }
         // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
         auto load_v = [&](int db) {
             const int row_a = lg * 4 + (li >> 2);
@@ -233,9 +271,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             return __builtin_bit_cast(
                 bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
         };
-        bf16x8 vr[3];
-        vr[0] = load_v(0);
-        vr[1] = load_v(1);
+        constexpr int VR = COLSUM ? 2 : 3;
+        bf16x8 vr[VR];
+#pragma unroll
+        for (int i = 0; i < VR - 1; ++i) vr[i] = load_v(i);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
@@ -281,7 +320,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             }
             pb[qb] = pk;
             if constexpr (COLSUM) {
-                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272)
+                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272).
+                // (this exact form is the only one hipcc allocates without scratch in the fused variant, which sits
+                // on the 256-VGPR cliff; the shipped path is the two-pass one, see chipmunk_dense_colsum_attn)
                 const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -302,15 +343,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
-            if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
+            if (db + VR - 1 < 8) vr[(db + VR - 1) % VR] = load_v(db + VR - 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pb[qb], o[qb][db]);
+            for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % VR], pb[qb], o[qb][db]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    if constexpr (COLSUM) {
+    if constexpr (COLSUM || CSONLY) {
         __syncthreads();
         if (ntiles > 0 && tid < KVT) {
             const int pos = (ntiles - 1) * KVT + tid;
@@ -319,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         }
     }
 
+    if constexpr (CSONLY) return;
     // ---- epilogue: O = O^T / l ; lane holds 4 consecutive d of one query row per (qb, db)
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
@@ -347,24 +389,28 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         }
         if constexpr (WRITE_L) {
             // l = 1 / (exp2(m*c) * norm) = 1 / sum_j exp(s_ij / sqrt(D))   (dense_attn.cu:225-227)
-            if (lg == 0) p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+            if (lg == 0) {
+                p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+                if (p.m_out) p.m_out[(int64_t)bh * p.Nq + qrow] = m[qb];
+            }
         }
     }
 }
 
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM>
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
 int launch_attn(const AttnParams &p, hipStream_t stream) {
-    auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, COLSUM>;
+    auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, COLSUM, CSONLY>;
+    constexpr int LDS = ATTN_LDS_BYTES - (CSONLY ? NST * TILE_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), ATTN_LDS_BYTES, stream, pp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, stream, pp);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -461,5 +507,22 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     p.l_out = l, p.p_in = pin, p.cs = (uint16_t *)cs, p.cs_stride = cs_stride;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
-    return launch_attn<false, false, true, true>(p, (hipStream_t)stream);
+    if (chipmunk_get_option("colsum_fused")) return launch_attn<false, false, true, true>(p, (hipStream_t)stream);
+    // Two passes (measured faster than the fused variant, which sits on the 256-VGPR cliff): (1) dense attention that
+    // also exports the final row max, (2) a K-only pass that recomputes S^T and reduces the column sums.
+    float *mbuf = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMallocAsync((void **)&mbuf, (size_t)B * H * Nq * sizeof(float), st) != hipSuccess) {
+        chipmunk_set_error("dense_colsum_attn: could not allocate %zu bytes of scratch", (size_t)B * H * Nq * sizeof(float));
+        return CHIPMUNK_ERR_LAUNCH;
+    }
+    p.m_out = mbuf;
+    int rc = launch_attn<false, false, true, false>(p, st);
+    if (rc == CHIPMUNK_OK) {
+        p.m_in = mbuf;
+        p.m_out = nullptr;
+        rc = launch_attn<false, false, false, false, true>(p, st);
+    }
+    (void)hipFreeAsync(mbuf, st);
+    return rc;
 }

@@ -34,6 +34,23 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+// round two floats to bf16 with the hardware converter (v_cvt_pk_bf16_f32, RNE) and widen them back
+__device__ __forceinline__ void round_bf16_pair(float &a, float &b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    a = __uint_as_float(u << 16);
+    b = __uint_as_float(u & 0xffff0000u);
+}
+// round-to-nearest-even to bf16 precision without the NaN special case (3 integer VALU ops); inf stays inf
+__device__ __forceinline__ float round_bf16_fast(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ float hw_round_bf16(float x) {
+    const __bf16 h = (__bf16)x;
+    return __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, h)) << 16);
+}
 // pack two floats to a dword of two bf16 (lo in bits 0-15)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
