@@ -43,6 +43,8 @@ struct AttnParams {
     int cs_stride;
     int B, H, Nq, Nk, G, idx_stride;
     float o_scale;
+    const int32_t *order;  // optional work order: block i processes (head, group) item order[i]
+    int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
 
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int wid = p.order ? p.order[wid0] : wid0;
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
 
@@ -397,6 +400,43 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 }
 
+// Longest-first work order for ragged key counts (HunyuanVideo: the text / tail query groups keep ALL 119k keys, 13x
+// the work of a normal group; dispatched last they leave a ~10 ms tail with two workgroups running).  Items whose
+// count exceeds twice the average go first; everything else keeps the natural (head, group) order, which is what keeps
+// one head's K/V hot in L2 / Infinity Cache.  One 1024-thread workgroup, a few microseconds.
+__global__ __launch_bounds__(1024) void attn_order_kernel(const int32_t *counts, int32_t *order, int n) {
+    __shared__ unsigned long long total;
+    __shared__ int n_heavy, wave_tot[16], base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) total = 0, n_heavy = 0, base_s = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int i = tid; i < n; i += 1024) mine += (unsigned)counts[i];
+    atomicAdd(&total, mine);
+    __syncthreads();
+    const long long thr = 2 * (long long)(total / (unsigned long long)n);
+    for (int i = tid; i < n; i += 1024)
+        if (counts[i] > thr) order[atomicAdd(&n_heavy, 1)] = i;
+    __syncthreads();
+    const int nh = n_heavy;
+    for (int i0 = 0; i0 < n; i0 += 1024) {  // ordered compaction of the light items
+        const int i = i0 + tid;
+        const bool light = i < n && counts[i] <= thr;
+        const unsigned long long bal = __ballot(light);
+        if (lane == 0) wave_tot[w] = __popcll(bal);
+        __syncthreads();
+        int off = base_s, tot = 0;
+        for (int j = 0; j < 16; ++j) {
+            off += j < w ? wave_tot[j] : 0;
+            tot += wave_tot[j];
+        }
+        if (light) order[nh + off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+}
+
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
 int launch_attn(const AttnParams &p, hipStream_t stream) {
     auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, COLSUM, CSONLY>;
@@ -410,7 +450,18 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     if (nblocks == 0) return CHIPMUNK_OK;
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
+    pp.xcd_chunks = chipmunk_get_option("attn_xcd_chunks");
+    int32_t *order = nullptr;
+    if (GATHER && nblocks >= 2048 && !chipmunk_get_option("attn_no_order")) {
+        if (hipMallocAsync((void **)&order, (size_t)nblocks * sizeof(int32_t), stream) != hipSuccess) order = nullptr;
+        if (order) {
+            hipLaunchKernelGGL(attn_order_kernel, dim3(1), dim3(1024), 0, stream, p.counts, order, (int)nblocks);
+            pp.order = order;
+            pp.xcd_chunks = 0;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, stream, pp);
+    if (order) (void)hipFreeAsync(order, stream);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

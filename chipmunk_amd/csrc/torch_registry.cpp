@@ -376,6 +376,28 @@ at::Tensor transpose_last2(at::Tensor x) {
     return out;
 }
 
+// ascending-order variant of (packed_)mask_to_indices (same set / counts / padding; see chipmunk_hip.h)
+std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef shape, int64_t multiple_of,
+                                               int64_t pad_to_multiple_of) {
+    CHECK_DEV(mask);
+    const bool packed = mask.scalar_type() == at::kByte;
+    TORCH_CHECK(packed || mask.scalar_type() == at::kBool, "mask must be bool, or uint8 bit-packed with a shape");
+    mask = mask.contiguous();
+    std::vector<int64_t> shp = packed ? shape.vec() : mask.sizes().vec();
+    TORCH_CHECK(shp.size() == 4, "shape must be [b, h, m, n]");
+    const int64_t b = shp[0], h = shp[1], m = shp[2], n = shp[3];
+    if (packed) TORCH_CHECK(n % 8 == 0 && mask.numel() * 8 >= b * h * m * n, "bad packed mask");
+    const int64_t pad_n = ((n + pad_to_multiple_of - 1) / pad_to_multiple_of) * pad_to_multiple_of;
+    c10::DeviceGuard guard(mask.device());
+    at::Tensor indices = at::empty({b, h, m, pad_n}, mask.options().dtype(at::kInt));
+    at::Tensor counts = at::empty({b, h, m}, mask.options().dtype(at::kInt));
+    check(chipmunk_mask_to_sorted_indices(mask.data_ptr(), packed ? 1 : 0, indices.data_ptr<int>(),
+                                          counts.data_ptr<int>(), b * h * m, (int)n, (int)pad_n, (int)multiple_of,
+                                          cur_stream(mask)),
+          "mask_to_sorted_indices");
+    return {indices, counts};
+}
+
 // reference src/chipmunk/ops/bitpack.py:4-69 as single kernels
 at::Tensor bitpack(at::Tensor mask) {
     TORCH_CHECK(mask.scalar_type() == at::kBool, "mask must be bool type");
@@ -421,6 +443,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
     m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
+    m.def("mask_to_sorted_indices(Tensor mask, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -441,6 +464,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("csp_mlp_mm1_fp8", &csp_mlp_mm1_fp8);
     m.impl("topk_delta_indices", &topk_delta_indices);
     m.impl("packed_mask_to_indices", &packed_mask_to_indices);
+    m.impl("mask_to_sorted_indices", &mask_to_sorted_indices);
     m.impl("transpose_last2", &transpose_last2);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);

@@ -82,6 +82,8 @@ class SparseDiffAttn(nn.Module):
             packed = self.storage.get_indices()
             shape = self.mask_shape[self.layer_counter.cur_model_invocation_per_step]
             if cfg.get("fused_packed_mask_to_indices", False) and packed.is_cuda and shape[-1] % 8 == 0:
+                if cfg.get("sorted_indices", False):
+                    return ops.mask_to_sorted_indices(packed, shape, multiple_of, bm)
                 return ops.packed_mask_to_indices(packed, shape, multiple_of, bm)
             return ops.mask_to_indices(ops.bitunpack(packed, shape), multiple_of, bm)
         return self.storage.get_indices(), self.storage.get_counts()
@@ -122,7 +124,10 @@ class SparseDiffAttn(nn.Module):
                     packed, mask_shape = ops.bitpack(mask)
                     self.mask_shape[self.layer_counter.cur_model_invocation_per_step] = mask_shape
                     self.storage.set_indices(packed)
-                    inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
+                    if mask.is_cuda and cfg.get("fused_packed_mask_to_indices", False) and cfg.get("sorted_indices", False):
+                        inds, counts = ops.mask_to_sorted_indices(mask, mask.shape, multiple_of, bm)
+                    else:
+                        inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
                 else:
                     kseq = k.shape[-2]
                     bs = bs[..., :_cdiv(kseq, bm), :kseq]

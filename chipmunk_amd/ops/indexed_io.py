@@ -29,3 +29,10 @@ def packed_mask_to_indices(packed: torch.Tensor, shape: Sequence[int], multiple_
                            pad_to_multiple_of: int) -> List[torch.Tensor]:
     """``mask_to_indices(bitunpack(packed, shape), ...)`` in one kernel (not in the reference)."""
     return torch.ops.chipmunk.packed_mask_to_indices(packed, list(shape), multiple_of, pad_to_multiple_of)
+
+
+def mask_to_sorted_indices(mask: torch.Tensor, shape: Sequence[int], multiple_of: int,
+                           pad_to_multiple_of: int) -> List[torch.Tensor]:
+    """Same kept set / counts / padding as ``mask_to_indices`` (``mask`` bool) or ``packed_mask_to_indices`` (``mask``
+    uint8 bit-packed, ``shape`` = original mask shape) with ASCENDING columns: sequential DRAM pages for the K/V gather."""
+    return torch.ops.chipmunk.mask_to_sorted_indices(mask, list(shape), multiple_of, pad_to_multiple_of)

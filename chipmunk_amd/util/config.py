@@ -77,12 +77,15 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "offloading.hbm_budget_gb": 200.0,
     # use the fused packed-bits -> indices kernel instead of bitunpack + mask_to_indices
     "attn.fused_packed_mask_to_indices": True,
+    # with the fused path: emit the kept keys in ascending order (same set; sequential DRAM pages for the gather)
+    "attn.sorted_indices": True,
     # one kernel for |block-mean delta| -> topk_indices -> copy_indices in the sparse MLP step (bm == mbm only)
     "mlp.fused_topk_delta": True,
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
 BASE_CONFIG["attn"]["fused_packed_mask_to_indices"] = AMD_EXTRA_KEYS["attn.fused_packed_mask_to_indices"]
+BASE_CONFIG["attn"]["sorted_indices"] = AMD_EXTRA_KEYS["attn.sorted_indices"]
 BASE_CONFIG["mlp"]["fused_topk_delta"] = AMD_EXTRA_KEYS["mlp.fused_topk_delta"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)

@@ -139,6 +139,12 @@ int chipmunk_mask_to_indices(const void *mask, int32_t *indices, int32_t *counts
 int chipmunk_packed_mask_to_indices(const void *packed, int32_t *indices, int32_t *counts, int64_t rows, int n,
                                     int pad_n, int multiple_of, void *stream);
 
+/* Same kept set, counts and padding columns as chipmunk_mask_to_indices, but the kept columns come out ASCENDING
+ * (packed != 0: input is the bit-packed mask).  Not the reference's order; for consumers that only need the set
+ * (the attention kernels): ascending keys make the K/V gather walk DRAM pages in order. */
+int chipmunk_mask_to_sorted_indices(const void *mask, int packed, int32_t *indices, int32_t *counts, int64_t rows,
+                                    int n, int pad_n, int multiple_of, void *stream);
+
 /* Replaces chipmunk::copy_indices (reference csrc/indexed_io/copy_indices.cu:82-154; schema chipmunk.cpp:57).
  * dst[b,row,idx] = src[b,row,idx] for the first counts[b,row/R] entries of inds[b,row/R,:]; elem_size 2 or 4. */
 int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const int32_t *counts, int B, int M, int R,

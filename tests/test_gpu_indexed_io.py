@@ -138,3 +138,22 @@ def test_topk_delta_indices_equals_unfused_sequence(dev, sparsity, multiple_of, 
 def test_transpose_last2(dev, shape):
     x = torch.randn(*shape).to(torch.bfloat16).to(dev)
     assert torch.equal(torch.ops.chipmunk.transpose_last2(x), x.transpose(-1, -2).contiguous())
+
+
+@pytest.mark.parametrize("shape,density", [((1, 2, 3, 4352), 0.15), ((1, 1, 4, 7488), 0.07), ((1, 1, 2, 200), 0.4)])
+def test_mask_to_sorted_indices_same_set_ascending(dev, shape, density):
+    import chipmunk_amd
+    mask = _rand_mask(shape, density, seed=11).to(dev)
+    ri, rc = torch.ops.chipmunk.mask_to_indices(mask, 128, 192)
+    si, sc = chipmunk_amd.ops.mask_to_sorted_indices(mask, mask.shape, 128, 192)
+    assert torch.equal(rc, sc) and si.shape == ri.shape
+    pop = mask.sum(-1)
+    for idx in [(0, 0, 0), (0, shape[1] - 1, shape[2] - 1)]:
+        n_true, n_all = int(pop[idx]), int(min(sc[idx], shape[-1]))
+        assert torch.equal(si[idx][:n_true], torch.nonzero(mask[idx]).flatten().to(torch.int32))   # ascending kept set
+        assert torch.equal(si[idx][n_true:n_all], ri[idx][n_true:n_all])                            # same padding
+    if shape[-1] % 8 == 0:
+        packed, shp = chipmunk_amd.ops.bitpack(mask)
+        pi, pc = chipmunk_amd.ops.mask_to_sorted_indices(packed, shp, 128, 192)
+        live = torch.arange(si.shape[-1], device=dev)[None, None, None, :] < sc.clamp(max=shape[-1])[..., None]
+        assert torch.equal(pc, sc) and torch.equal(pi[live], si[live])

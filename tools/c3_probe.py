@@ -53,8 +53,11 @@ def main():
         kind = "full" if full else "sparse"
         print(f"step {step} ({kind:6s}): {1e3 * dt / args.layers:9.2f} ms/layer   out finite: {bool(torch.isfinite(out.float()).all())}")
         if step == 1:
-            counts = layers[0].storage.get_indices()
-            print(f"  packed mask bytes: {counts.numel()}  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+            packed = layers[0].storage.get_indices()
+            shape = layers[0].mask_shape[0]
+            _, cnt = chipmunk_amd.ops.mask_to_sorted_indices(packed, shape, 128, 192)
+            print(f"  packed mask bytes: {packed.numel()}  counts mean {cnt.float().mean().item():.0f} min {cnt.min().item()} "
+                  f"max {cnt.max().item()}  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # consistency of the sparse step with the dense result on the same inputs (same q,k,v every step => delta ~ 0)
     o_dense, _ = chipmunk_amd.ops.dense_attn(q, k, v)
     err = (out.float() - o_dense.float()).abs().max().item()
