@@ -36,8 +36,6 @@ struct AttnParams {
     int64_t qs[3], ks[3], vs[3], os[3];
     const int32_t *indices, *counts;
     float *l_out;
-    float *m_out;       // optional: final running max per query row (scratch for the column-sum pass)
-    const float *m_in;  // CSONLY: that max, read back
     const float *p_in;
     uint16_t *cs;
     int cs_stride;
@@ -63,9 +61,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                 tile t+6 into the key ring) -> QK^T, online softmax, PV on tile t.
 //   The gather keys reach the lanes through LDS as well (global_load_lds_dword by wave 0, ds_read_b32 by everybody):
 //   an ordinary global load of the keys would make hipcc wait vmcnt(0) at its use and drain the DMA pipeline.
-// CSONLY = second pass of dense_colsum_attn: only K is staged, S^T is recomputed against the FINAL row max from the
-// first pass and reduced to the 192-row column sums; no softmax state, no V, no O accumulators (so it runs at twice the
-// occupancy).  exp2(s - m)*exp2(m) does not depend on which m centres it, only the bf16 rounding points move.
+// CSONLY = second pass of dense_colsum_attn: only K is staged, S^T is recomputed and reduced to the 192-row column sums;
+// no softmax state, no V, no O accumulators (so it runs at twice the occupancy).  The reference's summand
+// exp2(s*c - m*c) * (exp2(m*c) * prev_l) does not depend on the max that centres it, so the pass evaluates it as
+// exp2(s*c + log2(prev_l)) -- one fma, one exp2 and one add per score (the pass is VALU-bound: v_exp_f32 is quarter
+// rate, every other op saved is ~8% of its time) -- in fp32, without the reference's two intermediate bf16 roundings.
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,16 +107,19 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 
     float prevl[3] = {0.f, 0.f, 0.f};
-    float cs_msc[3] = {0.f, 0.f, 0.f}, cs_rowfac[3] = {0.f, 0.f, 0.f};  // CSONLY: per-row constants
+    float cs_off[3][4];  // CSONLY: log2(prev_l) of query row qb*16 + lg*4 + r (that pass computes S, not S^T)
     if constexpr (COLSUM || CSONLY) {
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
             const int qrow = row0 + qb * 16 + li;
             prevl[qb] = qrow < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qrow] : 0.f;
             if constexpr (CSONLY) {
-                cs_msc[qb] = (qrow < p.Nq ? p.m_in[(int64_t)bh * p.Nq + qrow] : 0.f) * SCALE_LOG2E;
-                // bf16(exp2(m*c) * prev_l)  (dense_colsum_attn.cu:268-271), with the final max
-                cs_rowfac[qb] = round_bf16(__builtin_amdgcn_exp2f(cs_msc[qb]) * prevl[qb]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = row0 + qb * 16 + lg * 4 + r;
+                    const float pl = qr < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
+                    cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -INFINITY;
+                }
             }
         }
         if (tid < 2 * KVT) cs_acc[tid] = 0.f;
@@ -202,6 +205,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         const unsigned char *Vb = Vl + slot * TILE_BYTES;
 
         // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
+        //      (CSONLY: S = Q . K^T with the operands swapped, s[qb][kt][r] = score(q = qb*16 + lg*4 + r, kv = kt*16 + li),
+        //       so that the sum over queries is mostly in-lane)
         f32x4 s[3][2];
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
@@ -225,9 +230,31 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 __builtin_amdgcn_sched_barrier(0);
                 const int kt = idx >> 2, ks = idx & 3;
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
+                for (int qb = 0; qb < 3; ++qb)
+                    s[qb][kt] = CSONLY ? mfma16(qf[qb][ks], kr[idx % FR], s[qb][kt]) : mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+
+        if constexpr (CSONLY) {
+            // exp2(s*c + log2 prev_l), summed over this wave's 48 queries: 12 in-lane terms, then the 4 lane rows
+            float cacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                float a = 0.f;
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        a += __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, cs_off[qb][r]));
+                cacc[kt] = t * KVT + kt * 16 + li < valid ? a : 0.f;
+            }
+            lane_swap32(cacc[0], cacc[1]);      // [0] = {kt0 rows 0-1, kt1 rows 0-1}, [1] = {kt0 rows 2-3, kt1 rows 2-3}
+            float x = cacc[0] + cacc[1], y = x;
+            lane_swap16(x, y);                  // x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3}
+            x += y;                             // lanes 0-15: key li of kt 0, lanes 32-47: key li of kt 1
+            if ((lane & 16) == 0) atomicAdd(cs_acc + (t & 1) * KVT + (lane >> 5) * 16 + li, x);
+            continue;
         }
         if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
 #pragma unroll
@@ -240,30 +267,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 }
         }
 
-        if constexpr (CSONLY) {
-            float cacc[2][4];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
-#pragma unroll
-            for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -cs_msc[qb]));
-                        cacc[kt][r] += round_bf16_fast(round_bf16_fast(pe) * cs_rowfac[qb]);
-                    }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float tot = row16_sum(cacc[kt][r]);
-                    if (li == 0) atomicAdd(cs_acc + (t & 1) * KVT + kt * 16 + lg * 4 + r, tot);
-                }
-            continue;
-        }
         // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
         auto load_v = [&](int db) {
             const int row_a = lg * 4 + (li >> 2);
@@ -394,7 +397,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             // l = 1 / (exp2(m*c) * norm) = 1 / sum_j exp(s_ij / sqrt(D))   (dense_attn.cu:225-227)
             if (lg == 0) {
                 p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
-                if (p.m_out) p.m_out[(int64_t)bh * p.Nq + qrow] = m[qb];
             }
         }
     }
@@ -559,21 +561,9 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
     if (chipmunk_get_option("colsum_fused")) return launch_attn<false, false, true, true>(p, (hipStream_t)stream);
-    // Two passes (measured faster than the fused variant, which sits on the 256-VGPR cliff): (1) dense attention that
-    // also exports the final row max, (2) a K-only pass that recomputes S^T and reduces the column sums.
-    float *mbuf = nullptr;
+    // Two passes (measured faster than the fused variant, which sits on the 256-VGPR cliff): (1) dense attention,
+    // (2) a K-only pass that recomputes S^T and reduces the column sums.  They share nothing but their inputs.
     hipStream_t st = (hipStream_t)stream;
-    if (hipMallocAsync((void **)&mbuf, (size_t)B * H * Nq * sizeof(float), st) != hipSuccess) {
-        chipmunk_set_error("dense_colsum_attn: could not allocate %zu bytes of scratch", (size_t)B * H * Nq * sizeof(float));
-        return CHIPMUNK_ERR_LAUNCH;
-    }
-    p.m_out = mbuf;
-    int rc = launch_attn<false, false, true, false>(p, st);
-    if (rc == CHIPMUNK_OK) {
-        p.m_in = mbuf;
-        p.m_out = nullptr;
-        rc = launch_attn<false, false, false, false, true>(p, st);
-    }
-    (void)hipFreeAsync(mbuf, st);
-    return rc;
+    const int rc = launch_attn<false, false, true, false>(p, st);
+    return rc != CHIPMUNK_OK ? rc : launch_attn<false, false, false, false, true>(p, st);
 }

@@ -25,6 +25,17 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// The same copy in buffer form: SGPR resource {base, 4 GiB range} + 32-bit per-lane byte offset + wave-uniform SGPR byte
+// offset.  No 64-bit per-lane address arithmetic, and measurably cheaper to issue next to MFMAs than the global form
+// (tools/probes/fill_rate.hip: GEMM-shaped stream + 16 MFMA per step, 107 -> 95 us).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off_bytes, uint32_t wave_off_bytes,
+                                       void *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off_bytes, (int)wave_off_bytes, 0, 0);
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even float -> bf16 bits (matches torch / the oracle's f2bf for finite values)
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
@@ -112,6 +123,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     int q = nblocks / NX, r = nblocks % NX;
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
+}
+
+// compute units of the current device (all devices of a node are the same part); 256 on MI355X
+inline int device_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
 }
 
 // ---- host-side error plumbing (thread-local message, see chipmunk_last_error) ----

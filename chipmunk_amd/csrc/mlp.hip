@@ -58,20 +58,43 @@ struct KTile {
 //     DIFFERENT groups over the same column-tile position gather overlapping weight rows, so the ~64 workgroups an XCD
 //     runs at once re-use each other's rows (and each group's activation tile) out of that XCD's 4 MiB L2 instead of
 //     re-fetching them through the fabric.  Measured on FLUX shapes: fabric fetch per launch 860 MB -> see DESIGN.md.
+//   * tail split (NSUB > 1): workgroups are dispatched in block order as slots free up, so with T equal tiles on S
+//     resident slots the last T mod S tiles run alone for a whole tile time (FLUX: 34 groups x 32 column tiles = 1088
+//     tiles on 512 slots -> the third "round" is 12 % full and costs a third of the launch).  When an XCD's leftover
+//     is small, each leftover tile is handed out as NSUB quarter-size sub-tiles (64 x 64 outputs, full K, deeper
+//     ring) to NSUB workgroups at the END of that XCD's block range.  Every output element is still produced by one
+//     workgroup with the same K order, so results are bit-identical to the unsplit schedule.
 struct TileMap {
-    int g, nt;
+    int g, nt, sub;  // sub < 0: whole tile
     bool live;
 };
 template <int BN>
-__device__ __forceinline__ TileMap map_tile(const int32_t *counts, int G, int NTmax, int NR) {
-    int cmax = 0;
-    for (int g = 0; g < G; ++g) cmax = max(cmax, counts[g]);
+__device__ __forceinline__ TileMap map_tile(const int32_t *counts, int G, int NTmax, int NR, int slots_per_xcd = 0,
+                                            int nsub = 1) {
+    int cmax = 0;  // wave-parallel max (a scalar loop over G costs ~50 ns per group, per workgroup)
+    for (int g = threadIdx.x & 63; g < G; g += 64) cmax = max(cmax, counts[g]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
     const int NTl = min((cmax + BN - 1) / BN, NTmax);
     const int total = NTl * G;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3;
     const int q = total >> 3, r = total & 7;
+    const int mine = q + (xcd < r ? 1 : 0);  // tiles of this XCD
     TileMap m;
-    m.live = slot < q + (xcd < r ? 1 : 0);
+    m.sub = -1;
+    int full = mine;
+    if (nsub > 1 && slots_per_xcd > 0) {
+        const int rem = mine % slots_per_xcd;
+        if (mine > slots_per_xcd && rem > 0 && rem * nsub <= slots_per_xcd) full = mine - rem;
+    }
+    if (slot >= full) {
+        const int k = slot - full;
+        m.sub = k % nsub;
+        slot = full + k / nsub;
+    }
+    m.live = slot < mine;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     const int per = G * NR;
     const int nb = t / per, rem = t - nb * per;
@@ -86,52 +109,73 @@ struct Mm1Params {
     const uint16_t *a, *b, *bias, *cache;
     uint16_t *c;
     const int32_t *indices, *counts;
-    int M, K, F, NT, NR, probe;
+    int M, K, F, NT, NR, probe, slots_per_xcd;
 };
 
-template <int BN, int BK, int NST, int WPS>
-__global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
+// One TM x TN output tile (TM rows of group g starting at m_off, packed columns n0 .. n0+TN-1): 4 waves as 2 x 2, each a
+// (TM/2) x (TN/2) accumulator of 32x32x16 MFMA tiles; NST-deep LDS ring of [A tile | B tile] stages.
+template <int TM, int TN, int BK, int NST>
+__device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem, int g, int m_off, int n0, int cnt) {
     using KT = KTile<BK>;
-    constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2, STAGE = A_TILE + B_TILE;
+    constexpr int A_TILE = TM * BK * 2, B_TILE = TN * BK * 2, STAGE = A_TILE + B_TILE;
     constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;  // DMA instructions per wave per tile
-    constexpr int NT4 = BN / 64;                                    // 32-wide n tiles per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int MT = TM / 64, NT4 = TN / 64;                      // 32-wide m / n tiles per wave
+    static_assert(A_INST >= 1 && B_INST >= 1, "tile too small for one DMA instruction per wave");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
-
-    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR);
-    if (!tm.live) return;
-    const int g = tm.g, nt = tm.nt;
-    const int cnt = p.counts[g];
-    const int n0 = nt * BN;
-    if (n0 >= cnt) return;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
     const int32_t *idxg = p.indices + (int64_t)g * p.F;
 
-    int aoff[A_INST], boff[B_INST];
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a), rb = make_rsrc(p.b);
+    uint32_t aoff[A_INST], boff[B_INST];  // byte offsets
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
         const int row = KT::lane_row(w * A_INST + i, lane);
-        aoff[i] = (g * BM + row) * p.K + KT::src_chunk_elems(row, lane);
+        aoff[i] = ((uint32_t)(g * BM + m_off + row) * p.K + KT::src_chunk_elems(row, lane)) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
         const int row = KT::lane_row(w * B_INST + i, lane);
         const int j = n0 + row;
         const int key = idxg[j < cnt ? j : n0];  // rows past the count re-read a live row and are never stored
-        boff[i] = key * p.K + KT::src_chunk_elems(row, lane);
+        boff[i] = ((uint32_t)key * p.K + KT::src_chunk_elems(row, lane)) * 2u;
     }
     auto issue = [&](int kb, int buf) {
         unsigned char *st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BK, st + (w * A_INST + i) * 1024);
+        for (int i = 0; i < A_INST; ++i) blds16(ra, aoff[i], kb * BK * 2, st + (w * A_INST + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < B_INST; ++i) glds16(p.b + boff[i] + kb * BK, st + A_TILE + (w * B_INST + i) * 1024);
+        for (int i = 0; i < B_INST; ++i) blds16(rb, boff[i], kb * BK * 2, st + A_TILE + (w * B_INST + i) * 1024);
+    };
+    // Epilogue operands staged through LDS when the tile's slice of the activation cache fits one ring stage: the
+    // TN x TM block cache[idx[n0..], g*BM+m_off ..] (TN rows of TM*2 contiguous bytes) is fetched by LDS-DMA during
+    // the LAST k step into the stage no tile needs any more, and the bf16 results leave through the other stage as
+    // 16-byte row-major stores.  (Direct form: 8-byte gathered loads and 2-byte stores, 64 of each per lane --
+    // measured 34 us of a 148 us launch.)
+    constexpr bool STAGED = TM * TN * 2 <= STAGE;
+    constexpr int LPR = TM * 2 / 16;                                  // 16-byte chunks per cache row
+    constexpr int C_INST = STAGED ? TM * TN * 2 / 4096 : 1;           // DMA instructions per wave
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.cache);
+    uint32_t coff[C_INST];
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int i = 0; i < C_INST; ++i) {
+            const int jj = (w * C_INST + i) * (64 / LPR) + lane / LPR;  // tile-local packed column
+            const int j = n0 + jj;
+            const int col = idxg[j < cnt ? j : n0];
+            coff[i] = ((uint32_t)col * p.M + g * BM + m_off + (((lane % LPR) ^ (jj & (LPR - 1))) << 3)) * 2u;
+        }
+    }
+    auto issue_cache = [&](int buf) {
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int i = 0; i < C_INST; ++i) blds16(rc, coff[i], 0, smem + buf * STAGE + (w * C_INST + i) * 1024);
+        }
     };
 
-    f32x16 acc[2][NT4];
+    f32x16 acc[MT][NT4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int n4 = 0; n4 < NT4; ++n4)
 #pragma unroll
@@ -148,6 +192,7 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kb + NST - 1 < nkb && p.probe != 1) issue(kb + NST - 1, nbuf);
+        if (kb == nkb - 1) issue_cache(nbuf);  // the stage tile kb-1 occupied is free for good
         if (p.probe == 2) {
             buf = buf + 1 == NST ? 0 : buf + 1;
             nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
@@ -158,13 +203,13 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
         // operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are in flight while the
         // MFMAs of slice kk issue (left to itself hipcc emits read -> lgkmcnt(0) -> 4 MFMA -> read ...)
         constexpr int KK = BK / 16;
-        bf16x8 af[2][2], bfr[2][NT4];
+        bf16x8 af[2][MT], bfr[2][NT4];
         auto load_frags = [&](int kk, int set) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[set][mt] = KT::frag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
+            for (int mt = 0; mt < MT; ++mt) af[set][mt] = KT::frag(At, wm * (TM / 2) + mt * 32 + (lane & 31), kk, lane);
 #pragma unroll
             for (int n4 = 0; n4 < NT4; ++n4)
-                bfr[set][n4] = KT::frag(Bt, wn * (BN / 2) + n4 * 32 + (lane & 31), kk, lane);
+                bfr[set][n4] = KT::frag(Bt, wn * (TN / 2) + n4 * 32 + (lane & 31), kk, lane);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -172,7 +217,7 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
             if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);  // keep the next slice's reads ahead of this slice's MFMAs
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int n4 = 0; n4 < NT4; ++n4)
                     acc[mt][n4] = mfma32(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4]);
@@ -182,36 +227,116 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 
+    if (p.probe == 4) {  // timing probe: no epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int n4 = 0; n4 < NT4; ++n4)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[mt][n4][r];
+        if (t == 123.456f) p.c[0] = 1;
+        return;
+    }
     // ---- epilogue: lane owns packed column j = lane&31 of each 32x32 tile and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     //      C[m,j] = bf16(gelu(acc + bias[idx]) - cache[idx, m])     (csp_mlp_mm1.cu:354-390)
+    if constexpr (STAGED) {
+        // after the loop: buf = stage after the last computed one = the cache stage (NST = 2) or a free one
+        const int last = buf == 0 ? NST - 1 : buf - 1;                  // stage of tile nkb-1
+        const int cst = last + NST - 1 >= NST ? last - 1 : last + NST - 1;  // nbuf at kb = nkb-1
+        unsigned char *Ct = smem + cst * STAGE, *Ot = smem + last * STAGE;
+        constexpr int LPO = TN * 2 / 16;  // 16-byte chunks per output row
+        wait_vmcnt<0>();
+        __syncthreads();  // cache block landed; every wave is done reading the last tile
 #pragma unroll
-    for (int n4 = 0; n4 < NT4; ++n4) {
-        const int j = n0 + wn * (BN / 2) + n4 * 32 + (lane & 31);
-        const bool live = j < cnt;
-        const int col = live ? idxg[j] : 0;
-        const float bia = bf16_bits_to_f32(p.bias[col]);
-        const uint16_t *crow = p.cache + (int64_t)col * p.M;
+        for (int n4 = 0; n4 < NT4; ++n4) {
+            const int jl = wn * (TN / 2) + n4 * 32 + (lane & 31);
+            const int j = n0 + jl;
+            const float bia = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int m = g * BM + wm * 64 + mt * 32 + q4 * 8 + (lane >> 5) * 4;
-                const u32x2 cv = *(const u32x2 *)(crow + m);
-                const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
-                const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
-                const float x0 = gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0;
-                const float x1 = gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1;
-                const float x2 = gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2;
-                const float x3 = gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3;
-                if (live) {
-                    uint16_t *cp = p.c + (int64_t)m * p.F + j;
-                    cp[0] = f32_to_bf16_bits(x0);
-                    cp[(int64_t)p.F] = f32_to_bf16_bits(x1);
-                    cp[2 * (int64_t)p.F] = f32_to_bf16_bits(x2);
-                    cp[3 * (int64_t)p.F] = f32_to_bf16_bits(x3);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int ml = wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                    const u32x2 cv = *(const u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2);
+                    const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
+                    const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
+                    const float x[4] = {gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0, gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1,
+                                        gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2, gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = ml + e;
+                        *(uint16_t *)(Ot + r * (TN * 2) + (((jl >> 3) ^ (r & (LPO - 1))) << 4) + (jl & 7) * 2) = f32_to_bf16_bits(x[e]);
+                    }
                 }
             }
         }
+        __syncthreads();
+        constexpr int O_INST = TM * TN * 2 / 4096;  // 1 KiB row-major pieces per wave
+#pragma unroll
+        for (int i = 0; i < O_INST; ++i) {
+            const int r = (w * O_INST + i) * (64 / LPO) + lane / LPO, ch = lane % LPO;
+            const u32x4 v = *(const u32x4 *)(Ot + r * (TN * 2) + ((ch ^ (r & (LPO - 1))) << 4));
+            const int j = n0 + ch * 8;
+            uint16_t *cp = p.c + (int64_t)(g * BM + m_off + r) * p.F + j;
+            if (j + 8 <= cnt && (p.F & 7) == 0) {
+                *(u32x4 *)cp = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (j + e < cnt) cp[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int n4 = 0; n4 < NT4; ++n4) {
+            const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
+            const bool live = j < cnt;
+            const int col = live ? idxg[j] : 0;
+            const float bia = bf16_bits_to_f32(p.bias[col]);
+            const uint16_t *crow = p.cache + (int64_t)col * p.M;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int m = g * BM + m_off + wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                    const u32x2 cv = *(const u32x2 *)(crow + m);
+                    const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
+                    const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
+                    const float x0 = gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0;
+                    const float x1 = gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1;
+                    const float x2 = gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2;
+                    const float x3 = gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3;
+                    if (live) {
+                        uint16_t *cp = p.c + (int64_t)m * p.F + j;
+                        cp[0] = f32_to_bf16_bits(x0);
+                        cp[(int64_t)p.F] = f32_to_bf16_bits(x1);
+                        cp[2 * (int64_t)p.F] = f32_to_bf16_bits(x2);
+                        cp[3 * (int64_t)p.F] = f32_to_bf16_bits(x3);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int BK, int NST, int WPS>
+__global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NSUB = 2 * (BN / 64);  // 64 x 64 sub-tiles per tile
+    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR, p.slots_per_xcd, NSUB);
+    if (!tm.live) return;
+    const int g = tm.g;
+    const int cnt = p.counts[g];
+    if (tm.sub < 0) {
+        const int n0 = tm.nt * BN;
+        if (n0 >= cnt) return;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
+        mm1_tile<BM, BN, BK, NST>(p, smem, g, 0, n0, cnt);
+    } else {
+        constexpr int SUB_NST = (NST * (BM + BN)) / 128;  // same LDS bytes, stages of 64 + 64 rows
+        const int n0 = tm.nt * BN + (tm.sub >> 1) * 64;
+        if (n0 >= cnt || p.probe == 3) return;  // probe 3: time the launch without its tail
+        mm1_tile<64, 64, BK, (SUB_NST > 4 ? 4 : SUB_NST)>(p, smem, g, (tm.sub & 1) * 64, n0, cnt);
     }
 }
 
@@ -629,7 +754,12 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s) {
     p.NT = (p.F + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
-    hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, s, p);
+    // tail split: WPS workgroups per CU are resident; the grid carries room for the sub-tile workgroups of each XCD
+    constexpr int NSUB = 2 * (BN / 64);
+    p.slots_per_xcd = chipmunk_get_option("mm1_no_split") ? 0 : WPS * device_cu_count() / 8;
+    const int per_xcd = ((p.M / BM) * p.NT + 7) / 8 + (p.slots_per_xcd > 0 ? p.slots_per_xcd : 0);
+    (void)NSUB;
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -641,7 +771,8 @@ extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const
     CM_CHECK(a && b && c && bias && pa_cache, "csp_mlp_mm1: null tensor pointer");
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
     CM_CHECK(K > 0 && K % 64 == 0, "csp_mlp_mm1: K must be a positive multiple of 64 (got %d)", K);
-    CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31), "csp_mlp_mm1: operand too large for 32-bit offsets");
+    CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31) && (int64_t)F * M < (1ll << 31),
+             "csp_mlp_mm1: operand too large for 32-bit offsets");
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (const uint16_t *)pa_cache,
                    (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe")};
     switch (chipmunk_get_option("mm1_variant")) {
