@@ -485,7 +485,7 @@ struct Mm2Params {
     const uint16_t *a, *b;  // a = packed [M,F], b = fc2^T [F,N2]
     uint16_t *c;            // [M,N2], accumulated in place
     const int32_t *indices, *counts;
-    int M, F, N2, NT, NR;
+    int M, F, N2, NT, NR, probe;
 };
 
 template <int BN, int BK, int NST, int WPS>
@@ -519,11 +519,12 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
     const int nkb = (cnt + BK - 1) / BK;
     if (nkb == 0) return;
 
-    int aoff[A_INST];
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a), rb = make_rsrc(p.b);
+    uint32_t aoff[A_INST];  // byte offsets
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
         const int row = KT::lane_row(w * A_INST + i, lane);
-        aoff[i] = (g * BM + row) * p.F + KT::src_chunk_elems(row, lane);
+        aoff[i] = ((uint32_t)(g * BM + row) * p.F + KT::src_chunk_elems(row, lane)) * 2u;
     }
     // The gather keys of a tile are wave-uniform per DMA row, so they are fetched with SCALAR loads (lgkmcnt): the
     // vector-memory counter then only counts LDS-DMA and the counted vmcnt pipeline below stays intact.  The keys of
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
     auto issue = [&](int kb, int buf) {
         unsigned char *st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BK, st + (w * A_INST + i) * 1024);
+        for (int i = 0; i < A_INST; ++i) blds16(ra, aoff[i], kb * BK * 2, st + (w * A_INST + i) * 1024);
 #pragma unroll
         for (int i = 0; i < B_INST; ++i) {
             int key = keys[i * BRPI];
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
             const int r = (w * B_INST + i) * BRPI + rsel;
             int chunk = (lane % BCPR) ^ ((r & 3) << 2);
             chunk = chunk * 8 < ncols ? chunk : 0;  // partial last column tile: stay inside the row
-            glds16(p.b + (int64_t)key * p.N2 + n0 + chunk * 8, st + A_TILE + (w * B_INST + i) * 1024);
+            blds16(rb, ((uint32_t)key * p.N2 + n0 + chunk * 8) * 2u, 0, st + A_TILE + (w * B_INST + i) * 1024);
         }
     };
 
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
         __builtin_amdgcn_s_barrier();
         if (kb + NST - 1 < nkb) {
             issue(kb + NST - 1, nbuf);
-            if (kb + NST < nkb) load_keys(kb + NST);
+            if (kb + NST < nkb) load_keys(kb + NST);  // (moving these behind the MFMAs measured 15 % slower)
         }
         const unsigned char *At = smem + buf * STAGE;
         const unsigned char *Bt = At + A_TILE;
@@ -619,6 +620,17 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 
+    if (p.probe == 4) {  // timing probe: no epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int n4 = 0; n4 < NT4; ++n4)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[n4][mt][r];
+        if (t == 123.456f) p.c[0] = 1;
+        return;
+    }
     // ---- epilogue: lane owns row m = lane&31 of each tile and 4 consecutive n per accumulator quad
     //      C = bf16(acc) + C in bf16  (triton/csp_mlp_mm2.py:100-101)
 #pragma unroll
@@ -726,8 +738,8 @@ int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
 int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, const int32_t *counts, int M, int F, int N2,
                hipStream_t s) {
     CM_CHECK(N2 > 0 && N2 % 8 == 0, "mm2: N2 must be a positive multiple of 8 (got %d)", N2);
-    CM_CHECK((int64_t)M * F < (1ll << 31), "mm2: M*F too large for 32-bit offsets");
-    Mm2Params p = {(const uint16_t *)a, (const uint16_t *)b, (uint16_t *)c, indices, counts, M, F, N2, 0, 0};
+    CM_CHECK((int64_t)M * F < (1ll << 31) && (int64_t)F * N2 < (1ll << 31), "mm2: M*F or F*N2 too large for 32-bit offsets");
+    Mm2Params p = {(const uint16_t *)a, (const uint16_t *)b, (uint16_t *)c, indices, counts, M, F, N2, 0, 0, chipmunk_get_option("mm1_probe")};
     switch (chipmunk_get_option("mm2_variant")) {
         case 1: return launch_mm2_variant<256, 64, 2, 1>(p, s);
         case 2: return launch_mm2_variant<128, 64, 2, 2>(p, s);
