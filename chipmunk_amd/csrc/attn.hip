@@ -41,6 +41,11 @@ struct AttnParams {
     int cs_stride;
     int B, H, Nq, Nk, G, idx_stride;
     float o_scale;
+    // key-split tail (see launch_attn): items >= split_full are handed to `nsplit` workgroups, each over a slice of the
+    // item's key tiles; partial (o, m, l) go through `ws`, the last arriver (ticket) merges and runs the epilogue
+    int split_full, nsplit;
+    float *ws;
+    int32_t *tickets;
     const int32_t *order;  // optional work order: block i processes (head, group) item order[i]
     int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
@@ -79,7 +84,15 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
 
-    const int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int sp = 0, nsp = 1, tail_item = 0;
+    if (!COLSUM && !CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
+        const int k = wid0 - p.split_full;
+        tail_item = k / p.nsplit;
+        sp = k - tail_item * p.nsplit;
+        nsp = p.nsplit;
+        wid0 = p.split_full + tail_item;
+    }
     const int wid = p.order ? p.order[wid0] : wid0;
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
@@ -88,6 +101,12 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
     const int valid = count < p.Nk ? count : p.Nk;
     const int ntiles = (valid + KVT - 1) / KVT;
+    if (!COLSUM && !CSONLY && nsp > 1) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
+        const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
+        nsp = nsp < cap ? nsp : cap;
+        if (sp >= nsp) return;
+    }
+    const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
     const int32_t *idx = GATHER ? p.indices + ((int64_t)bh * p.G + g) * p.idx_stride : nullptr;
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
@@ -163,24 +182,24 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     float lsum[3] = {0.f, 0.f, 0.f};
 
     // ---- prologue: keys of tiles 0..NST-2 synchronously, then the data of those tiles (+ keys NST-1 .. 2NST-3)
-    if (ntiles > 0) {
+    if (tend > tbeg) {
 #pragma unroll
-        for (int T = 0; T < NST - 1; ++T) issue_keys(T);
+        for (int T = 0; T < NST - 1; ++T) issue_keys(tbeg + T);
         wait_vmcnt<0>();
         __syncthreads();
 #pragma unroll
         for (int T = 0; T < NST - 1; ++T) {
-            if (T < ntiles) {
-                issue_data(T);
-                issue_keys(T + NST - 1);
+            if (tbeg + T < tend) {
+                issue_data(tbeg + T);
+                issue_keys(tbeg + T + NST - 1);
             }
         }
     }
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tbeg; t < tend; ++t) {
         const int slot = t % NST;
         // tile t has landed once at most the NST-2 younger groups (4 DMAs each, +1 key DMA on wave 0) are in flight
-        if (t + NST - 1 <= ntiles) {
+        if (t + NST - 1 <= tend) {
             constexpr int L = CSONLY ? 2 : 4;  // DMA instructions per wave per tile
             if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
             else wait_vmcnt<(NST - 2) * L>();
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 *acc = 0.f;
             }
         }
-        if (t + NST - 1 < ntiles && p.probe != 1) {
+        if (t + NST - 1 < tend && p.probe != 1) {
             issue_data(t + NST - 1);
             issue_keys(t + 2 * (NST - 1));
         }
@@ -367,6 +386,53 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 
     if constexpr (CSONLY) return;
+    if (!COLSUM && nsp > 1) {
+        // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
+        //      arriver folds the other slices in (the lane layout is the same in every slice, so the merge is the
+        //      online-softmax rescale element by element) and alone runs the epilogue.
+        //      Visibility: write-through (sc1) stores -> drained -> barrier -> relaxed agent-scope ticket; the consumer's
+        //      loads bypass its L1 (sc1), so no fence on either side (MI355X_MICROARCH.md, hand-offs / publish-large).
+        int *ticket_s = (int *)cs_acc;
+        f32x4 *mine = (f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + sp) * (26 * 256) + tid;
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int db = 0; db < 8; ++db) store16_sc1(mine + (qb * 8 + db) * 256, o[qb][db]);
+        store16_sc1(mine + 24 * 256, (f32x4){m[0], m[1], m[2], 0.f});
+        store16_sc1(mine + 25 * 256, (f32x4){lsum[0], lsum[1], lsum[2], 0.f});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            *ticket_s = __hip_atomic_fetch_add(p.tickets + tail_item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*ticket_s != nsp - 1) return;
+        if (tid == 0)  // leave the ticket at zero for the next launch
+            __hip_atomic_store(p.tickets + tail_item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int s2 = 0; s2 < nsp; ++s2) {
+            if (s2 == sp) continue;
+            const f32x4 *oth = (const f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + s2) * (26 * 256) + tid;
+            f32x4 ms, ls, pad0 = {}, pad1 = {};
+            load16_sc1(ms, oth + 24 * 256);
+            load16_sc1(ls, oth + 25 * 256);
+            wait_sc1_loads(ms, ls, pad0, pad1);
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                f32x4 v[8];
+#pragma unroll
+                for (int db = 0; db < 8; ++db) load16_sc1(v[db], oth + (qb * 8 + db) * 256);
+                wait_sc1_loads(v[0], v[1], v[2], v[3]);
+                wait_sc1_loads(v[4], v[5], v[6], v[7]);
+                const float m_new = fmaxf(m[qb], ms[qb]);
+                if (m_new == -INFINITY) continue;  // both slices empty
+                const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
+                const float c = __builtin_amdgcn_exp2f((ms[qb] - m_new) * SCALE_LOG2E);
+                m[qb] = m_new;
+                lsum[qb] = lsum[qb] * a + ls[qb] * c;
+#pragma unroll
+                for (int db = 0; db < 8; ++db) o[qb][db] = o[qb][db] * a + v[db] * c;
+            }
+        }
+    }
     // ---- epilogue: O = O^T / l ; lane holds 4 consecutive d of one query row per (qb, db)
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
@@ -453,17 +519,40 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
     pp.xcd_chunks = chipmunk_get_option("attn_xcd_chunks");
-    int32_t *order = nullptr;
+    // scratch layout: [tickets: TICKET_BYTES, always left at zero][work order | split partials]
+    constexpr size_t TICKET_BYTES = 64 << 10;
     if (GATHER && nblocks >= 2048 && !chipmunk_get_option("attn_no_order")) {
-        if (hipMallocAsync((void **)&order, (size_t)nblocks * sizeof(int32_t), stream) != hipSuccess) order = nullptr;
-        if (order) {
+        unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, TICKET_BYTES + (size_t)nblocks * sizeof(int32_t));
+        if (sc) {
+            int32_t *order = (int32_t *)(sc + TICKET_BYTES);
             hipLaunchKernelGGL(attn_order_kernel, dim3(1), dim3(1024), 0, stream, p.counts, order, (int)nblocks);
             pp.order = order;
             pp.xcd_chunks = 0;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, stream, pp);
-    if (order) (void)hipFreeAsync(order, stream);
+    // Key-split tail.  Workgroups are dispatched in block order as the 2-per-CU slots free up; with near-equal items
+    // the last (nblocks mod slots) of them run alone for a full item time (FLUX: 24 heads x 23 groups = 552 items on
+    // 512 slots -> half of the launch is a 8 %-full second round).  Those items (or all of them when the whole grid
+    // is under half the machine) are split over their key tiles into up to 8 workgroups each.
+    int64_t grid = nblocks;
+    if (!COLSUM && !CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split")) {
+        const int64_t slots = 2 * (int64_t)device_cu_count();
+        const int64_t rem = nblocks <= slots / 2 ? nblocks : nblocks % slots;
+        if (rem > 0 && rem * 2 <= slots && rem * sizeof(int32_t) <= TICKET_BYTES) {
+            int f = (int)(slots / rem);
+            f = f > 8 ? 8 : f;
+            const size_t ws_bytes = (size_t)rem * f * 26 * 256 * sizeof(f32x4);
+            unsigned char *sc = f > 1 ? (unsigned char *)chipmunk_scratch(stream, TICKET_BYTES + ws_bytes) : nullptr;
+            if (sc) {
+                pp.tickets = (int32_t *)sc;
+                pp.ws = (float *)(sc + TICKET_BYTES);
+                pp.nsplit = f;
+                pp.split_full = (int)(nblocks - rem);
+                grid = (nblocks - rem) + rem * f;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, pp);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

@@ -17,7 +17,7 @@ extern "C" int chipmunk_abi_version(void) { return 1; }
 #include <string.h>
 namespace {
 struct Option { const char *name; int value; };
-Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"colsum_fused", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}};
+Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"colsum_fused", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}};
 }
 int chipmunk_get_option(const char *name) {
     for (auto &o : g_options) if (strcmp(o.name, name) == 0) return o.value;
@@ -27,4 +27,39 @@ extern "C" int chipmunk_set_option(const char *name, int value) {
     for (auto &o : g_options) if (strcmp(o.name, name) == 0) { o.value = value; return CHIPMUNK_OK; }
     chipmunk_set_error("unknown option '%s'", name);
     return CHIPMUNK_ERR_INVALID;
+}
+
+// ---- per-(device, stream) scratch: schedule arrays, split-K partials, arrival tickets ----
+// Grow-only, zero-filled when (re)allocated, contents persist between launches (kernels that use tickets leave them at
+// zero).  Keyed by stream so that launches on different streams never share a buffer; launches on one stream are
+// ordered, which is all the users need.  A stream-ordered hipMallocAsync/hipFreeAsync pair per launch measured tens of
+// microseconds of host time -- more than the kernels it served.
+#include <map>
+#include <mutex>
+#include <utility>
+namespace {
+struct Scratch { void *ptr; size_t bytes; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+}
+void *chipmunk_scratch(hipStream_t stream, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    Scratch &s = g_scratch[{dev, stream}];
+    if (s.bytes >= bytes) return s.ptr;
+    if (s.ptr) {
+        (void)hipStreamSynchronize(stream);  // earlier launches on this stream may still be using the old buffer
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr, s.bytes = 0;
+    }
+    const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    void *ptr = nullptr;
+    if (hipMalloc(&ptr, want) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(ptr, 0, want, stream) != hipSuccess) {
+        (void)hipFree(ptr);
+        return nullptr;
+    }
+    s.ptr = ptr, s.bytes = want;
+    return ptr;
 }

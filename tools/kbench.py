@@ -86,7 +86,7 @@ def bench_attn(which, variants):
     if "hunyuan" in which:
         H, N, count = int(os.environ.get('KB_HEADS', '6')), 119056, 7296   # BASELINE C3 counts; KB_HEADS=24 for all heads
     else:
-        H, N, count = 24, 4352, 672
+        H, N, count = 24, 4352, int(os.environ.get('KB_COUNT', '672'))
     q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
     G = (N + 191) // 192
     for var in variants:
