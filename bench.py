@@ -141,6 +141,7 @@ def build_flux(dev, n_layers, timer):
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, _mm2_work)
     import chipmunk_amd.ops as ops_pkg
     ops_pkg.csp_attn_inplace = timer.wrap("csp_attn", ops_pkg.csp_attn_inplace, _csp_attn_work)
+    ops_pkg.csp_attn_out = timer.wrap("csp_attn", ops_pkg.csp_attn_out, _csp_attn_work)   # sparse-step form
 
     H, N, D, HID, FFN = 24, 4352, 128, 3072, 12288
     n_double = max(1, round(n_layers * 19 / 57))

@@ -33,6 +33,7 @@ constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * KVT * 4;
 struct AttnParams {
     const uint16_t *q, *k, *v;
     uint16_t *o;
+    const uint16_t *o_in;  // INPLACE only: the accumulation base (o itself for the in-place op, the cache for csp_attn_out)
     int64_t qs[3], ks[3], vs[3], os[3];
     const int32_t *indices, *counts;
     float *l_out;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 z = {};
-            qf[qb][ks] = qrow < p.Nq ? *(const bf16x8 *)(qp + ks * 32 + lg * 8) : z;
+            qf[qb][ks] = (qrow < p.Nq && !(p.probe & 8)) ? *(const bf16x8 *)(qp + ks * 32 + lg * 8) : z;
         }
     }
 
@@ -215,11 +216,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 *acc = 0.f;
             }
         }
-        if (t + NST - 1 < tend && p.probe != 1) {
+        if (t + NST - 1 < tend && (p.probe & 3) != 1) {
             issue_data(t + NST - 1);
             issue_keys(t + 2 * (NST - 1));
         }
-        if (p.probe == 2) continue;
+        if ((p.probe & 3) == 2) continue;
         const unsigned char *Kb = Kl + slot * TILE_BYTES;
         const unsigned char *Vb = Vl + slot * TILE_BYTES;
 
@@ -440,15 +441,24 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
         const int qrow = row0 + qb * 16 + li;
         if (qrow >= p.Nq) continue;
-        uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + lg * 4;
-        if (INPLACE && ntiles == 0) continue;
+        const int64_t ooff = b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + lg * 4;
+        uint16_t *op = p.o + ooff;
+        const uint16_t *oin = INPLACE ? p.o_in + ooff : nullptr;
+        if (INPLACE && ntiles == 0) {  // nothing to add: in place leaves o alone, out of place copies the base
+            if (oin != op) {
+#pragma unroll
+                for (int db = 0; db < 8; ++db) *(u32x2 *)(op + db * 16) = *(const u32x2 *)(oin + db * 16);
+            }
+            continue;
+        }
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
             float x0 = o[qb][db][0] * inv, x1 = o[qb][db][1] * inv, x2 = o[qb][db][2] * inv, x3 = o[qb][db][3] * inv;
             u32x2 out;
             if constexpr (INPLACE) {
                 // bf16 store of o_scale*result, then bf16 reduce-add into o (csp_attn.cu:294-300)
-                const u32x2 old = *(const u32x2 *)(op + db * 16);
+                u32x2 old = {0u, 0u};
+                if (!(p.probe & 4)) old = *(const u32x2 *)(oin + db * 16);
                 const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
                 const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
                 out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 out[0] = pack_bf16x2(x0, x1);
                 out[1] = pack_bf16x2(x2, x3);
             }
-            *(u32x2 *)(op + db * 16) = out;
+            if (!(p.probe & 16) || out[0] == 0x12345678u) *(u32x2 *)(op + db * 16) = out;
         }
         if constexpr (WRITE_L) {
             // l = 1 / (exp2(m*c) * norm) = 1 / sum_j exp(s_ij / sqrt(D))   (dense_attn.cu:225-227)
@@ -592,6 +602,29 @@ extern "C" int chipmunk_csp_attn(const void *q, const void *k, const void *v, vo
     if (int e = check_strides(o_strides, "o")) return e;
     AttnParams p = {};
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i], p.os[i] = o_strides[i];
+    p.indices = indices, p.counts = counts;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
+    p.o_scale = (float)o_scale;
+    p.o_in = p.o;
+    return launch_attn<true, true, false, false>(p, (hipStream_t)stream);
+}
+
+extern "C" int chipmunk_csp_attn_out(const void *q, const void *k, const void *v, const void *o_in, void *o_out,
+                                     const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                                     const int64_t o_strides[3], const int32_t *indices, const int32_t *counts, int B,
+                                     int H, int Nq, int Nk, int idx_stride, int o_scale, void *stream) {
+    if (int e = check_common(q, k, v, o_out, B, H, Nq, Nk)) return e;
+    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 7) == 0, "csp_attn_out: o_in missing or not 8-byte aligned");
+    CM_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
+    CM_CHECK(indices && counts, "csp_attn_out: indices / counts missing");
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    if (int e = check_strides(o_strides, "o")) return e;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o_out;
+    p.o_in = (const uint16_t *)o_in;
     for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i], p.os[i] = o_strides[i];
     p.indices = indices, p.counts = counts;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;

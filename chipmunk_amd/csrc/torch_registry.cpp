@@ -84,6 +84,27 @@ void csp_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor o, at::Tensor
           "csp_attn");
 }
 
+// addition: o_in + o_scale * sparse attention into a fresh tensor (the clone + in-place pair of modules/attn.py:186-188)
+at::Tensor csp_attn_out(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor o_in, at::Tensor indices,
+                        at::Tensor indices_counts, int64_t o_scale) {
+    check_attn_shapes(q, k, v);
+    CHECK_DEV(o_in); CHECK_BF16(o_in);
+    TORCH_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
+    TORCH_CHECK(o_in.sizes() == q.sizes(), "O must have the shape of Q");
+    const int64_t groups = (q.size(2) + 191) / 192;
+    check_indices(q, indices, indices_counts, groups);
+    c10::DeviceGuard guard(q.device());
+    at::Tensor oi = o_in.contiguous();
+    at::Tensor o = at::empty(q.sizes(), oi.options());
+    auto qs = strides_of(q, "Q"), ks = strides_of(k, "K"), vs = strides_of(v, "V"), os = strides_of(o, "O");
+    check(chipmunk_csp_attn_out(q.data_ptr(), k.data_ptr(), v.data_ptr(), oi.data_ptr(), o.data_ptr(), qs.s, ks.s, vs.s,
+                                os.s, indices.data_ptr<int>(), indices_counts.data_ptr<int>(), (int)q.size(0),
+                                (int)q.size(1), (int)q.size(2), (int)k.size(2), (int)indices.size(3), (int)o_scale,
+                                cur_stream(q)),
+          "csp_attn_out");
+    return o;
+}
+
 // reference csrc/attn/csp_128_attn.cu:355-461
 at::Tensor csp_128_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor indices, at::Tensor indices_counts) {
     check_attn_shapes(q, k, v);
@@ -439,6 +460,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("mask_to_indices(Tensor mask, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
 
     // additions (not in the reference): native GEMM2 entry, fused packed-mask path, single-kernel bit packing
+    m.def("csp_attn_out(Tensor q, Tensor k, Tensor v, Tensor o_in, Tensor indices, Tensor indices_counts, int o_scale) -> Tensor");
     m.def("csp_mlp_mm2(Tensor mma_a, Tensor mma_b, Tensor indices, Tensor counts, Tensor(mma_c!) mma_c) -> ()");
     m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
     m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
@@ -460,6 +482,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("csp_128_attn", &csp_128_attn);
     m.impl("dense_attn", &dense_attn);
     m.impl("dense_colsum_attn", &dense_colsum_attn);
+    m.impl("csp_attn_out", &csp_attn_out);
     m.impl("csp_mlp_mm2", &csp_mlp_mm2);
     m.impl("csp_mlp_mm1_fp8", &csp_mlp_mm1_fp8);
     m.impl("topk_delta_indices", &topk_delta_indices);

@@ -146,6 +146,8 @@ class SparseDiffAttn(nn.Module):
 
             if do_padding:
                 o_cache = o - ops.csp_attn(q, k, v, inds, counts)
+            elif o.is_cuda and cfg.get("fused_residual", True):
+                o_cache = ops.csp_attn_out(q, k, v, o, inds, counts, -1)
             else:
                 o_cache = o.clone()
                 ops.csp_attn_inplace(q, k, v, o_cache, inds, counts, -1)
@@ -157,6 +159,8 @@ class SparseDiffAttn(nn.Module):
         o = self.storage.get_out_cache()
         if do_padding:
             return o + ops.csp_attn(q, k, v, inds, counts)
+        if o.is_cuda and cfg.get("fused_residual", True) and not self.storage.out_cache.is_offload_enabled:
+            return ops.csp_attn_out(q, k, v, o, inds, counts, 1)  # cache + delta in one kernel, cache untouched
         if not self.storage.out_cache.is_offload_enabled:
             o = o.clone()  # the kernel accumulates in place and the cache must survive (reference attn.py:186-188)
         ops.csp_attn_inplace(q, k, v, o, inds, counts, 1)

@@ -12,6 +12,10 @@ def _register():
     def _(q, k, v, indices, indices_counts):
         return torch.empty_like(q)
 
+    @lib.register_fake("chipmunk::csp_attn_out")
+    def _(q, k, v, o_in, indices, indices_counts, o_scale):
+        return torch.empty(q.shape, dtype=o_in.dtype, device=o_in.device)
+
     @lib.register_fake("chipmunk::dense_attn")
     def _(q, k, v):
         return [torch.empty(q.shape, dtype=q.dtype, device=q.device),

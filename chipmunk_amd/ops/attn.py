@@ -68,4 +68,11 @@ def csp_attn_inplace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch
     torch.ops.chipmunk.csp_attn(q, k, v, o, indices, indices_counts, o_scale)
 
 
-__all__ = ["csp_attn", "csp_attn_inplace", "dense_attn", "dense_colsum_attn"]
+def csp_attn_out(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o_in: torch.Tensor, indices: torch.Tensor,
+                 indices_counts: torch.Tensor, o_scale: int) -> torch.Tensor:
+    """``o_in + o_scale * sparse_attention`` into a new tensor: the reference's ``o = cache.clone(); csp_attn(..., o, ...)``
+    pair (``modules/attn.py:186-188``) as one kernel, without the copy."""
+    return torch.ops.chipmunk.csp_attn_out(q, k, v, o_in, indices, indices_counts, o_scale)
+
+
+__all__ = ["csp_attn", "csp_attn_inplace", "csp_attn_out", "dense_attn", "dense_colsum_attn"]

@@ -81,12 +81,15 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "attn.sorted_indices": True,
     # one kernel for |block-mean delta| -> topk_indices -> copy_indices in the sparse MLP step (bm == mbm only)
     "mlp.fused_topk_delta": True,
+    # sparse attention step as ONE kernel (cache + delta -> new tensor) instead of clone + in-place accumulate
+    "attn.fused_residual": True,
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
 BASE_CONFIG["attn"]["fused_packed_mask_to_indices"] = AMD_EXTRA_KEYS["attn.fused_packed_mask_to_indices"]
 BASE_CONFIG["attn"]["sorted_indices"] = AMD_EXTRA_KEYS["attn.sorted_indices"]
 BASE_CONFIG["mlp"]["fused_topk_delta"] = AMD_EXTRA_KEYS["mlp.fused_topk_delta"]
+BASE_CONFIG["attn"]["fused_residual"] = AMD_EXTRA_KEYS["attn.fused_residual"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
 

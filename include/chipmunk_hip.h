@@ -53,6 +53,14 @@ int chipmunk_csp_attn(const void *q, const void *k, const void *v, void *o, cons
                       const int32_t *indices, const int32_t *counts, int B, int H, int Nq, int Nk, int idx_stride,
                       int o_scale, void *stream);
 
+/* Out-of-place form of chipmunk_csp_attn: o_out = o_in + bf16(o_scale * sparse_attention), o_in untouched; o_in and
+ * o_out share `o_strides`.  It replaces the `o = out_cache.clone(); csp_attn(q, k, v, o, ...)` pair of the reference's
+ * sparse step (src/chipmunk/modules/attn.py:186-188): same bytes, one kernel, no 2 x B*H*N*128*2-byte copy. */
+int chipmunk_csp_attn_out(const void *q, const void *k, const void *v, const void *o_in, void *o_out,
+                          const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                          const int64_t o_strides[3], const int32_t *indices, const int32_t *counts, int B, int H,
+                          int Nq, int Nk, int idx_stride, int o_scale, void *stream);
+
 /* Replaces chipmunk::csp_128_attn (reference csrc/attn/csp_128_attn.cu:355-461; schema csrc/chipmunk.cpp:53).
  * Same math, out of place into `o` (contiguous [B,H,Nq,128] bf16, fully overwritten), contiguous q/k/v. */
 int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,

@@ -81,6 +81,26 @@ def test_csp_attn_inplace_random_indices(dev, n, count, o_scale):
     assert_close_bf16(o, o_ref, atol=3e-2, what="csp_attn in place")
 
 
+@pytest.mark.parametrize("o_scale", [1, -1])
+def test_csp_attn_out_equals_clone_plus_inplace(dev, o_scale):
+    """csp_attn_out == `o = base.clone(); csp_attn(q, k, v, o, ...)` bit for bit (same kernel, different base
+    pointer), leaves the base untouched, and copies the base for a group that keeps no key."""
+    H, n, count = 2, 1100, 336
+    q, k, v = _qkv(1, H, n, n, seed=13)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, count, n, seed=6)
+    counts[0, 1, 2] = 0
+    base = randn_bf16(1, H, n, 128, seed=98).to(dev)
+    keep = base.clone()
+    qd, kd, vd, indd, cntd = q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev)
+    ref = base.clone()
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, ref, indd, cntd, o_scale)
+    out = torch.ops.chipmunk.csp_attn_out(qd, kd, vd, base, indd, cntd, o_scale)
+    assert torch.equal(base, keep)
+    assert torch.equal(out, ref)
+    assert torch.equal(out[0, 1, 2 * 192:3 * 192], base[0, 1, 2 * 192:3 * 192])
+
+
 def test_csp_attn_strided_qkv(dev):
     n, H, count = 768, 3, 224
     base = [randn_bf16(1, n, H, 128, seed=s) for s in (21, 22, 23)]

@@ -15,7 +15,8 @@ def main(path, steps=20, per_step=55):
     first = mm1[-steps * per_step]
     # step boundary: walk back from the first mm1 of the window to the start of that step (first kernel after the
     # previous step's last mm2/scatter) -- approximate by starting at the mm1 itself and ending one step-length later
-    last = len(rows) - 1
+    # the timed region ends with the GEMM2 that follows the last GEMM1 (bench.py's probes / work sums come after it)
+    last = next(i for i in range(mm1[-1], len(rows)) if "mm2_kernel" in rows[i][0])
     t0, t1 = rows[first][1], rows[last][2]
     agg, cnt = collections.Counter(), collections.Counter()
     busy = 0
