@@ -113,6 +113,15 @@ def _mm2_work(packed, unpacked, indices, counts, spacked, fc2wT, cached_out, *a,
     return work
 
 
+def _mm2_only_work(packed, fc2wT, indices, counts, cached_out, *a, **k):
+    M, F = packed.shape
+    N2 = fc2wT.shape[1]
+    def work():
+        c = float(counts.sum().item())
+        return 2.0 * 128 * c * N2, c * 256 + c * N2 * 2 + 2 * M * N2 * 2
+    return work
+
+
 def _csp_attn_work(q, k, v, o, indices, counts, o_scale):
     B, H, N, D = q.shape
     def work():
@@ -139,6 +148,9 @@ def build_flux(dev, n_layers, timer):
     # event brackets around the three sparse-step kernels
     mlp_ops.mm1 = timer.wrap("csp_mlp_mm1", mlp_ops.mm1, _mm1_work)
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, _mm2_work)
+    # shipped split of the same work (config mlp.fused_scatter): GEMM1 applies the scatter-add, GEMM2 runs alone
+    mlp_ops.mm1_scatter = timer.wrap("csp_mlp_mm1+scatter_add", mlp_ops.mm1_scatter, _mm1_work)
+    mlp_ops.csp_mlp_mm2 = timer.wrap("csp_mlp_mm2", mlp_ops.csp_mlp_mm2, _mm2_only_work)
     import chipmunk_amd.ops as ops_pkg
     ops_pkg.csp_attn_inplace = timer.wrap("csp_attn", ops_pkg.csp_attn_inplace, _csp_attn_work)
     ops_pkg.csp_attn_out = timer.wrap("csp_attn", ops_pkg.csp_attn_out, _csp_attn_work)   # sparse-step form
@@ -196,7 +208,8 @@ def pmc_traffic(op_name):
         return None
     with open(path) as f:
         t = json.load(f)
-    parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"]}
+    parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
+             "csp_mlp_mm1+scatter_add": ["mm1", "scatter_add"], "csp_mlp_mm2": ["mm2"]}
     keys = parts.get(op_name, [])
     if not keys or any(k not in t for k in keys):
         return None

@@ -106,10 +106,12 @@ __device__ __forceinline__ TileMap map_tile(const int32_t *counts, int G, int NT
 
 // ------------------------------------------------------------------------------------------------ mm1
 struct Mm1Params {
-    const uint16_t *a, *b, *bias, *cache;
+    const uint16_t *a, *b, *bias;
+    uint16_t *cache;
     uint16_t *c;
     const int32_t *indices, *counts;
     int M, K, F, NT, NR, probe, slots_per_xcd;
+    int update_cache;  // 1: also apply the scatter-add of this tile's deltas to the cache block it already holds in LDS
 };
 
 // One TM x TN output tile (TM rows of group g starting at m_off, packed columns n0 .. n0+TN-1): 4 waves as 2 x 2, each a
@@ -263,10 +265,19 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                     const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
                     const float x[4] = {gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0, gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1,
                                         gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2, gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3};
+                    float xr[4];  // the packed deltas as stored (bf16)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = ml + e;
-                        *(uint16_t *)(Ot + r * (TN * 2) + (((jl >> 3) ^ (r & (LPO - 1))) << 4) + (jl & 7) * 2) = f32_to_bf16_bits(x[e]);
+                        const uint16_t xb = f32_to_bf16_bits(x[e]);
+                        xr[e] = bf16_bits_to_f32(xb);
+                        *(uint16_t *)(Ot + r * (TN * 2) + (((jl >> 3) ^ (r & (LPO - 1))) << 4) + (jl & 7) * 2) = xb;
+                    }
+                    if (p.update_cache) {  // cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
+                        u32x2 nc;
+                        nc[0] = pack_bf16x2(c0 + xr[0], c1 + xr[1]);
+                        nc[1] = pack_bf16x2(c2 + xr[2], c3 + xr[3]);
+                        *(u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2) = nc;
                     }
                 }
             }
@@ -285,6 +296,14 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (j + e < cnt) cp[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+        if (p.update_cache) {  // the updated cache block goes back the way it came: 1 KiB pieces, TM*2-byte row segments
+#pragma unroll
+            for (int i = 0; i < C_INST; ++i) {
+                const int jj = (w * C_INST + i) * (64 / LPR) + lane / LPR;
+                if (n0 + jj < cnt)
+                    *(u32x4 *)((unsigned char *)p.cache + coff[i]) = *(const u32x4 *)(Ct + (w * C_INST + i) * 1024 + lane * 16);
             }
         }
     } else {
@@ -754,8 +773,9 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
 }
 
 template <int BN, int BK, int NST, int WPS>
-int launch_mm1_variant(const Mm1Params &p0, hipStream_t s) {
+int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated = nullptr) {
     constexpr int LDS = NST * (BM * BK * 2 + BN * BK * 2);
+    constexpr bool STAGED = BM * BN * 2 <= (BM + BN) * BK * 2;  // mm1_tile's staged epilogue (the one that can scatter)
     auto kern = mm1_kernel<BN, BK, NST, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -763,6 +783,8 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s) {
         attr_set = true;
     }
     Mm1Params p = p0;
+    if (!STAGED) p.update_cache = 0;
+    if (cache_updated) *cache_updated = p.update_cache != 0;
     p.NT = (p.F + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
@@ -778,26 +800,42 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const void *bias, const void *pa_cache,
-                                    const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream) {
+namespace {
+int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_cache, const int32_t *indices,
+              const int32_t *counts, int M, int K, int F, hipStream_t stream, int update_cache, bool *cache_updated) {
     CM_CHECK(a && b && c && bias && pa_cache, "csp_mlp_mm1: null tensor pointer");
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
     CM_CHECK(K > 0 && K % 64 == 0, "csp_mlp_mm1: K must be a positive multiple of 64 (got %d)", K);
     CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31) && (int64_t)F * M < (1ll << 31),
              "csp_mlp_mm1: operand too large for 32-bit offsets");
-    Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (const uint16_t *)pa_cache,
-                   (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe")};
+    Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache,
+                   (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache};
     switch (chipmunk_get_option("mm1_variant")) {
-        case 1: return launch_mm1_variant<256, 64, 2, 1>(p, (hipStream_t)stream);
-        case 3: return launch_mm1_variant<128, 64, 3, 1>(p, (hipStream_t)stream);
-        case 4: return launch_mm1_variant<256, 32, 3, 2>(p, (hipStream_t)stream);
-        case 5: return launch_mm1_variant<256, 64, 3, 1>(p, (hipStream_t)stream);
-        case 6: return launch_mm1_variant<128, 32, 4, 2>(p, (hipStream_t)stream);
-        case 7: return launch_mm1_variant<128, 32, 3, 3>(p, (hipStream_t)stream);
-        case 8: return launch_mm1_variant<128, 64, 2, 3>(p, (hipStream_t)stream);
-        case 9: return launch_mm1_variant<128, 64, 2, 4>(p, (hipStream_t)stream);
-        default: return launch_mm1_variant<128, 64, 2, 2>(p, (hipStream_t)stream);  // measured best (profiles/r01_*)
+        case 1: return launch_mm1_variant<256, 64, 2, 1>(p, stream, cache_updated);
+        case 3: return launch_mm1_variant<128, 64, 3, 1>(p, stream, cache_updated);
+        case 4: return launch_mm1_variant<256, 32, 3, 2>(p, stream, cache_updated);
+        case 5: return launch_mm1_variant<256, 64, 3, 1>(p, stream, cache_updated);
+        case 6: return launch_mm1_variant<128, 32, 4, 2>(p, stream, cache_updated);
+        case 7: return launch_mm1_variant<128, 32, 3, 3>(p, stream, cache_updated);
+        case 8: return launch_mm1_variant<128, 64, 2, 3>(p, stream, cache_updated);
+        case 9: return launch_mm1_variant<128, 64, 2, 4>(p, stream, cache_updated);
+        default: return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*)
     }
+}
+}  // namespace
+
+extern "C" int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const void *bias, const void *pa_cache,
+                                    const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream) {
+    return mm1_entry(a, b, c, bias, const_cast<void *>(pa_cache), indices, counts, M, K, F, (hipStream_t)stream, 0, nullptr);
+}
+
+extern "C" int chipmunk_csp_mlp_mm1_scatter(const void *a, const void *b, void *c, const void *bias, void *pa_cache,
+                                            const int32_t *indices, const int32_t *counts, int M, int K, int F,
+                                            void *stream) {
+    bool done = false;
+    if (int e = mm1_entry(a, b, c, bias, pa_cache, indices, counts, M, K, F, (hipStream_t)stream, 1, &done)) return e;
+    // tile shapes whose epilogue does not hold the cache block in LDS: the separate scatter-add kernel
+    return done ? CHIPMUNK_OK : launch_scatter_add(c, pa_cache, indices, counts, M, F, (hipStream_t)stream);
 }
 
 extern "C" int chipmunk_csp_scatter_add(const void *packed, void *unpacked_colmajor, const int32_t *indices,

@@ -185,6 +185,29 @@ void csp_mlp_mm1(at::Tensor a, at::Tensor b_colmajor, at::Tensor c, at::Tensor b
           "csp_mlp_mm1");
 }
 
+// addition: GEMM1 + the scatter-add of its output into the activation cache, one kernel
+void csp_mlp_mm1_scatter(at::Tensor a, at::Tensor b_colmajor, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
+                         at::Tensor indices, at::Tensor indices_counts) {
+    CHECK_DEV(a); CHECK_DEV(b_colmajor); CHECK_DEV(c); CHECK_DEV(bias); CHECK_DEV(pa_cache_colmajor);
+    CHECK_DEV(indices); CHECK_DEV(indices_counts);
+    CHECK_BF16(a); CHECK_BF16(b_colmajor); CHECK_BF16(c); CHECK_BF16(bias); CHECK_BF16(pa_cache_colmajor);
+    CHECK_I32(indices); CHECK_I32(indices_counts);
+    CHECK_CONTIG(a); CHECK_CONTIG(b_colmajor); CHECK_CONTIG(c); CHECK_CONTIG(bias); CHECK_CONTIG(pa_cache_colmajor);
+    CHECK_CONTIG(indices); CHECK_CONTIG(indices_counts);
+    TORCH_CHECK(a.dim() == 2 && b_colmajor.dim() == 2 && c.dim() == 2, "a, b_colmajor, c must be 2D");
+    const int64_t M = a.size(0), K = a.size(1), F = b_colmajor.size(0);
+    TORCH_CHECK(b_colmajor.size(1) == K, "a and b_colmajor must share the K dimension");
+    TORCH_CHECK(c.size(0) == M && c.size(1) == F, "c must be [M, F]");
+    TORCH_CHECK(bias.numel() == F, "bias must have F entries");
+    TORCH_CHECK(pa_cache_colmajor.numel() == F * M, "pa_cache_colmajor must be [F, M]");
+    TORCH_CHECK(indices.numel() == (M / 128) * F && indices_counts.numel() == M / 128, "indices must be [M/128, F], counts [M/128]");
+    c10::DeviceGuard guard(a.device());
+    check(chipmunk_csp_mlp_mm1_scatter(a.data_ptr(), b_colmajor.data_ptr(), c.data_ptr(), bias.data_ptr(),
+                                       pa_cache_colmajor.data_ptr(), indices.data_ptr<int>(),
+                                       indices_counts.data_ptr<int>(), (int)M, (int)K, (int)F, cur_stream(a)),
+          "csp_mlp_mm1_scatter");
+}
+
 // native counterpart of the reference's Triton csp_mlp_mm1_fp8 (src/chipmunk/triton/csp_mlp_mm1.py:143-164)
 void csp_mlp_mm1_fp8(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
                      at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b,
@@ -461,6 +484,7 @@ TORCH_LIBRARY(chipmunk, m) {
 
     // additions (not in the reference): native GEMM2 entry, fused packed-mask path, single-kernel bit packing
     m.def("csp_attn_out(Tensor q, Tensor k, Tensor v, Tensor o_in, Tensor indices, Tensor indices_counts, int o_scale) -> Tensor");
+    m.def("csp_mlp_mm1_scatter(Tensor a, Tensor b_colmajor, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts) -> ()");
     m.def("csp_mlp_mm2(Tensor mma_a, Tensor mma_b, Tensor indices, Tensor counts, Tensor(mma_c!) mma_c) -> ()");
     m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
     m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
@@ -483,6 +507,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("dense_attn", &dense_attn);
     m.impl("dense_colsum_attn", &dense_colsum_attn);
     m.impl("csp_attn_out", &csp_attn_out);
+    m.impl("csp_mlp_mm1_scatter", &csp_mlp_mm1_scatter);
     m.impl("csp_mlp_mm2", &csp_mlp_mm2);
     m.impl("csp_mlp_mm1_fp8", &csp_mlp_mm1_fp8);
     m.impl("topk_delta_indices", &topk_delta_indices);

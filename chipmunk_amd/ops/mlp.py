@@ -11,6 +11,7 @@ from typing import Optional
 
 import torch
 
+from ..util.config import GLOBAL_CONFIG
 from .indexed_io import scatter_add
 
 USE_FUSED_MLP_MATMUL_2 = True
@@ -33,6 +34,13 @@ def mm1(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc
         csp_mlp_mm1_fp8(x, fc1w, fc1b, indices, counts, sparse_act_T, sparse_act_packed, scale_a, scale_b)
     else:
         raise ValueError(f"Unsupported dtype: {fc1w.dtype}")
+
+
+def mm1_scatter(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc1b: torch.Tensor,
+                sparse_act_T: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor) -> None:
+    """GEMM1 + ``csp_scatter_add`` of its output into ``sparse_act_T`` in one kernel (bf16 only)."""
+    assert x.dtype == torch.bfloat16 and sparse_act_packed.dtype == torch.bfloat16 and sparse_act_T.dtype == torch.bfloat16
+    torch.ops.chipmunk.csp_mlp_mm1_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
 
 
 FP8_MM1_UPDATES_CACHE = False
@@ -89,6 +97,12 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
     K2_, _N = fc2w_T.shape
     assert K2 == K2_, "K2 must match"
     sparse_act_packed = torch.empty((M, K2), device=x.device, dtype=sparse_act_T.dtype)  # bf16 also when x is fp8
+    if (x.is_cuda and fc1w.dtype == torch.bfloat16
+            and GLOBAL_CONFIG["mlp"].get("fused_scatter", True)):
+        # GEMM1 applies the scatter-add of its own deltas (same bits as the two-kernel form), GEMM2 runs alone
+        mm1_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
+        csp_mlp_mm2(sparse_act_packed, fc2w_T, indices, counts, cached_out)
+        return
     mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts, mm1_scale_a, mm1_scale_b)
     if USE_FUSED_MLP_MATMUL_2:
         mm2_fused(sparse_act_packed, sparse_act_T, indices, counts, sparse_act_packed, fc2w_T, cached_out,
@@ -97,4 +111,4 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
         mm2_unfused(sparse_act_packed, fc2w_T, cached_out, sparse_act_T, indices, counts, num_sms_scatter_add)
 
 
-__all__ = ["mm1", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2", "csp_mlp_mm1_fp8"]
+__all__ = ["mm1", "mm1_scatter", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2", "csp_mlp_mm1_fp8"]

@@ -90,6 +90,14 @@ int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, cons
 int chipmunk_csp_mlp_mm1(const void *a, const void *b, void *c, const void *bias, const void *pa_cache,
                          const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream);
 
+/* GEMM1 that also applies the scatter-add of its own output: after computing c as above,
+ *   pa_cache[idx[g,j], m] = bf16(pa_cache[idx[g,j], m] + c[m,j])          (== chipmunk_csp_scatter_add(c, pa_cache, ...))
+ * from the cache block the epilogue already holds in LDS.  Bit-identical to chipmunk_csp_mlp_mm1 followed by
+ * chipmunk_csp_scatter_add; saves that kernel's launch and its re-read of c and the cache.  Each (group, column) block of
+ * the cache is read and written by exactly one workgroup. */
+int chipmunk_csp_mlp_mm1_scatter(const void *a, const void *b, void *c, const void *bias, void *pa_cache,
+                                 const int32_t *indices, const int32_t *counts, int M, int K, int F, void *stream);
+
 /* fp8 (OCP e4m3fn) GEMM1 for BASELINE config C5: native counterpart of the reference's Triton csp_mlp_mm1_fp8
  * (src/chipmunk/triton/csp_mlp_mm1.py:37-164).  a [M,K] fp8, b [F,K] fp8; scale_a / scale_b: device pointers to ONE
  * fp32 each (the reference passes 0-dim tensors holding the RECIPROCAL quantisation scales, modules/mlp.py:98-99):

@@ -63,6 +63,33 @@ def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts):
         assert (c[g * 128:(g + 1) * 128, n:].float() == sentinel).all()
 
 
+@pytest.mark.parametrize("variant", [0, 4])  # 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel
+@pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]),
+                                          (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)])])
+def test_mm1_scatter_equals_mm1_then_scatter_add(dev, M, K, F, counts, variant):
+    """csp_mlp_mm1_scatter == csp_mlp_mm1 followed by csp_scatter_add, bit for bit, in c AND in the cache (the last
+    shape has 34 groups x 8 column tiles: it exercises the tail-split 64x64 sub-tiles as well)."""
+    from chipmunk_amd import _native
+    a, b = randn_bf16(M, K, seed=1, scale=0.5), randn_bf16(F, K, seed=2, scale=0.1)
+    bias, cache = randn_bf16(F, seed=3, scale=0.2), randn_bf16(F, M, seed=4, scale=0.3)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    inds = _index_rows(M // 128, F, counts, seed=5)
+    ad, bd, biasd, indd, cntd = a.to(dev), b.to(dev), bias.to(dev), inds.to(dev), cnt.to(dev)
+    c_ref = torch.full((M, F), 7.0, dtype=torch.bfloat16, device=dev)
+    cache_ref = cache.clone().to(dev)
+    torch.ops.chipmunk.csp_mlp_mm1(ad, bd, c_ref, biasd, cache_ref, indd, cntd)
+    torch.ops.chipmunk.csp_scatter_add(c_ref[None], cache_ref[None], indd[None], cntd[None], 6)
+    c = torch.full((M, F), 7.0, dtype=torch.bfloat16, device=dev)
+    cache_new = cache.clone().to(dev)
+    _native.set_option("mm1_variant", variant)
+    try:
+        torch.ops.chipmunk.csp_mlp_mm1_scatter(ad, bd, c, biasd, cache_new, indd, cntd)
+    finally:
+        _native.set_option("mm1_variant", 0)
+    assert torch.equal(c.view(torch.int16), c_ref.view(torch.int16))
+    assert torch.equal(cache_new.view(torch.int16), cache_ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,F,counts", [(256, 512, [64, 192]), (384, 1024, [1024, 8, 320])])
 def test_scatter_add(dev, M, F, counts):
     packed = randn_bf16(M, F, seed=11)
