@@ -391,38 +391,38 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
         //      arriver folds the other slices in (the lane layout is the same in every slice, so the merge is the
         //      online-softmax rescale element by element) and alone runs the epilogue.
-        //      Visibility: write-through (sc1) stores -> drained -> barrier -> relaxed agent-scope ticket; the consumer's
-        //      loads bypass its L1 (sc1), so no fence on either side (MI355X_MICROARCH.md, hand-offs / publish-large).
+        //      Visibility: plain stores -> barrier -> one agent-scope release (L2 write-back) -> drained -> relaxed ticket;
+        //      last arriver: ticket -> one agent-scope acquire -> barrier -> plain loads (MI355X_MICROARCH.md, hand-offs).
+        //      (A fence-free variant on write-through stores and L1-bypassing loads issued through inline asm produced
+        //      wrong elements at HunyuanVideo scale in one build and none in the next: loads the compiler cannot see
+        //      are not worth ~1 % of a launch.)
         int *ticket_s = (int *)cs_acc;
         f32x4 *mine = (f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + sp) * (26 * 256) + tid;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
-            for (int db = 0; db < 8; ++db) store16_sc1(mine + (qb * 8 + db) * 256, o[qb][db]);
-        store16_sc1(mine + 24 * 256, (f32x4){m[0], m[1], m[2], 0.f});
-        store16_sc1(mine + 25 * 256, (f32x4){lsum[0], lsum[1], lsum[2], 0.f});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int db = 0; db < 8; ++db) mine[(qb * 8 + db) * 256] = o[qb][db];
+        mine[24 * 256] = (f32x4){m[0], m[1], m[2], 0.f};
+        mine[25 * 256] = (f32x4){lsum[0], lsum[1], lsum[2], 0.f};
         __syncthreads();
-        if (tid == 0)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait (see guide)
             *ticket_s = __hip_atomic_fetch_add(p.tickets + tail_item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         if (*ticket_s != nsp - 1) return;
-        if (tid == 0)  // leave the ticket at zero for the next launch
-            __hip_atomic_store(p.tickets + tail_item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(p.tickets + tail_item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
         for (int s2 = 0; s2 < nsp; ++s2) {
             if (s2 == sp) continue;
             const f32x4 *oth = (const f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + s2) * (26 * 256) + tid;
-            f32x4 ms, ls, pad0 = {}, pad1 = {};
-            load16_sc1(ms, oth + 24 * 256);
-            load16_sc1(ls, oth + 25 * 256);
-            wait_sc1_loads(ms, ls, pad0, pad1);
+            const f32x4 ms = oth[24 * 256], ls = oth[25 * 256];
 #pragma unroll
             for (int qb = 0; qb < 3; ++qb) {
-                f32x4 v[8];
-#pragma unroll
-                for (int db = 0; db < 8; ++db) load16_sc1(v[db], oth + (qb * 8 + db) * 256);
-                wait_sc1_loads(v[0], v[1], v[2], v[3]);
-                wait_sc1_loads(v[4], v[5], v[6], v[7]);
                 const float m_new = fmaxf(m[qb], ms[qb]);
                 if (m_new == -INFINITY) continue;  // both slices empty
                 const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 m[qb] = m_new;
                 lsum[qb] = lsum[qb] * a + ls[qb] * c;
 #pragma unroll
-                for (int db = 0; db < 8; ++db) o[qb][db] = o[qb][db] * a + v[db] * c;
+                for (int db = 0; db < 8; ++db) o[qb][db] = o[qb][db] * a + oth[(qb * 8 + db) * 256] * c;
             }
         }
     }
@@ -545,7 +545,10 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // 512 slots -> half of the launch is a 8 %-full second round).  Those items (or all of them when the whole grid
     // is under half the machine) are split over their key tiles into up to 8 workgroups each.
     int64_t grid = nblocks;
-    if (!COLSUM && !CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split")) {
+    // Dense launches only by default: a gathered FLUX item is ~45 us of which ~11 us are fixed costs every slice pays
+    // again, and the split measured 94 -> 105 us there (option attn_split_gather forces it, for the tests).
+    if (!COLSUM && !CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
+        (!GATHER || chipmunk_get_option("attn_split_gather"))) {
         const int64_t slots = 2 * (int64_t)device_cu_count();
         const int64_t rem = nblocks <= slots / 2 ? nblocks : nblocks % slots;
         if (rem > 0 && rem * 2 <= slots && rem * sizeof(int32_t) <= TICKET_BYTES) {

@@ -36,21 +36,6 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off_bytes, (int)wave_off_bytes, 0, 0);
 }
 
-// 16-byte write-through store / L1-bypassing load (sc1): the cheap way to hand tens of KB from one workgroup to another
-// inside a launch -- no release/acquire fence pair (those write back / invalidate whole caches; MI355X_MICROARCH.md
-// "publish-large": 3.0 vs 8.2 us per 64 KB).  Producer: sc1 stores -> s_waitcnt vmcnt(0) -> ticket; consumer: ticket
-// -> sc1 loads.  The loads are asynchronous and invisible to the compiler: call wait_sc1_loads on the destination
-// registers before using them.
-__device__ __forceinline__ void store16_sc1(void *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void load16_sc1(f32x4 &v, const void *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void wait_sc1_loads(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
-
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even float -> bf16 bits (matches torch / the oracle's f2bf for finite values)
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {

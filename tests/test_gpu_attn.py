@@ -101,6 +101,28 @@ def test_csp_attn_out_equals_clone_plus_inplace(dev, o_scale):
     assert torch.equal(out[0, 1, 2 * 192:3 * 192], base[0, 1, 2 * 192:3 * 192])
 
 
+def test_csp_attn_key_split_forced(dev):
+    """The key-split tail is off for gathered launches by default (it does not pay at FLUX sizes); forced on, the in-place
+    gathered kernel must still match the oracle -- including ragged counts, a group with no keys and slices of 0 tiles."""
+    from chipmunk_amd import _native
+    H, n = 2, 1100
+    q, k, v = _qkv(1, H, n, n, seed=17)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, 672, n, seed=8)
+    counts[0, 0, 1] = 0
+    counts[0, 1, 3] = 96
+    o0 = randn_bf16(1, H, n, 128, seed=97)
+    o_ref = o0.clone()
+    oracle.csp_attn(q, k, v, o_ref, inds, counts, 1)
+    o = o0.clone().to(dev)
+    _native.set_option("attn_split_gather", 1)
+    try:
+        torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), o, inds.to(dev), counts.to(dev), 1)
+    finally:
+        _native.set_option("attn_split_gather", 0)
+    assert_close_bf16(o, o_ref, atol=3e-2, what="csp_attn with forced key split")
+
+
 def test_csp_attn_strided_qkv(dev):
     n, H, count = 768, 3, 224
     base = [randn_bf16(1, n, H, 128, seed=s) for s in (21, 22, 23)]

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--heads", type=int, default=24)
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (repeatable)")
+    ap.add_argument("--cfg", action="append", default=[], help="config override section.key=value (repeatable)")
     args = ap.parse_args()
     import chipmunk_amd
     from chipmunk_amd.util import config as cfg
@@ -28,6 +30,14 @@ def main():
     from chipmunk_amd.modules import SparseDiffAttn
     cfg.load_from_file(os.path.join(ROOT, "configs", "hunyuan_c3.yml"))
     cfg.GLOBAL_CONFIG["attn"]["first_n_dense_layers"] = 0
+    from chipmunk_amd import _native
+    for o in args.opt:
+        name, val = o.split("=")
+        _native.set_option(name, int(val))
+    for o in args.cfg:
+        key, val = o.split("=")
+        sec, name = key.split(".")
+        cfg.GLOBAL_CONFIG[sec][name] = {"true": True, "false": False}.get(val.lower(), val)
     dev = torch.device("cuda:0")
     vid, txt = (33, 45, 80), 256
     N = vid[0] * vid[1] * vid[2] + txt
@@ -60,8 +70,15 @@ def main():
                   f"max {cnt.max().item()}  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # consistency of the sparse step with the dense result on the same inputs (same q,k,v every step => delta ~ 0)
     o_dense, _ = chipmunk_amd.ops.dense_attn(q, k, v)
-    err = (out.float() - o_dense.float()).abs().max().item()
+    d = (out.float() - o_dense.float()).abs()
+    err = d.max().item()
     print(f"sparse-step output vs dense on identical inputs: max abs diff {err:.4f}")
+    bad = (d > 1e-3).nonzero()
+    print(f"  elements off by more than 1e-3: {bad.shape[0]} of {d.numel()}; |o| max {o_dense.float().abs().max().item():.3f}")
+    if bad.shape[0]:
+        rows = bad[:, 2]
+        print(f"  heads {sorted(set(bad[:, 1].tolist()))[:8]}  rows min {rows.min().item()} max {rows.max().item()}  "
+              f"row groups {sorted(set((rows // 192).tolist()))[:12]}")
 
 
 if __name__ == "__main__":
