@@ -202,14 +202,14 @@ def build_flux(dev, n_layers, timer):
 def pmc_traffic(op_name):
     """HBM bytes per launch of the op's kernels from the committed PMC run (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kbench.py at the C2 single-block shape, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md).  bench.py cannot collect counters itself; None if the file is absent."""
+    per MI355X_MICROARCH.md; regenerate with tools/collect_pmc_traffic.py).  bench.py cannot collect counters itself; None if the file is absent."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f)
     parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
-             "csp_mlp_mm1+scatter_add": ["mm1", "scatter_add"], "csp_mlp_mm2": ["mm2"]}
+             "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"]}
     keys = parts.get(op_name, [])
     if not keys or any(k not in t for k in keys):
         return None

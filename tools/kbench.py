@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmark at the BASELINE shapes: back-to-back launches inside one HIP-event bracket, so the
 number is kernel time (comparable with rocprofv3's average duration), not host launch latency.
 
-usage: python tools/kbench.py [mm1 mm2 scatter csp_flux csp_hunyuan dense_flux colsum_flux topk m2i copy] [--variants 0,1,2]
+usage: python tools/kbench.py [mm1 mm1s mm2 scatter csp_flux csp_hunyuan dense_flux colsum_flux topk m2i copy] [--variants 0,1,2]
 """
 import argparse
 import os
@@ -60,6 +60,10 @@ def bench_mlp(which, variants, M=4352, K=3072, F=12288, keep=4096):
             _native.set_option("mm1_variant", v)
             ms = timeit(lambda: torch.ops.chipmunk.csp_mlp_mm1(a, w1, packed, bias, cache, inds, counts))
             print(f"mm1   variant {v}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s   (M={M} K={K} keep={keep})")
+        elif which == "mm1s":
+            _native.set_option("mm1_variant", v)
+            ms = timeit(lambda: torch.ops.chipmunk.csp_mlp_mm1_scatter(a, w1, packed, bias, cache, inds, counts))
+            print(f"mm1+scatter v{v}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s   (M={M} K={K} keep={keep})")
         elif which == "mm2":
             _native.set_option("mm2_variant", v)
             ms = timeit(lambda: torch.ops.chipmunk.csp_mlp_mm2(packed, w2t, inds, counts, out))
@@ -154,7 +158,7 @@ def main():
         _native.set_option(name, int(val))
     variants = [int(x) for x in args.variants.split(",")]
     for w in args.what:
-        if w in ("mm1", "mm2", "scatter"):
+        if w in ("mm1", "mm1s", "mm2", "scatter"):
             bench_mlp(w, variants)
         elif w in ("topk", "m2i", "copy"):
             bench_io(w)
