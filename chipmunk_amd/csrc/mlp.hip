@@ -507,19 +507,22 @@ struct Mm2Params {
     int M, F, N2, NT, NR, probe;
 };
 
-template <int BN, int BK, int NST, int WPS>
-__global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
+template <int BN, int BK, int NST, int WPS, int NW = 4>
+__global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2Params p) {
+    static_assert(NW == 4 || NW == 8, "4 waves (2 x 2) or 8 waves (2 x 4)");
+    constexpr int WNG = NW / 2;                 // waves along n; wave tile = 64 rows x BN/WNG columns
     using KT = KTile<BK>;
     constexpr int A_TILE = BM * BK * 2, B_TILE = BK * BN * 2, STAGE = A_TILE + B_TILE;
-    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;
-    constexpr int NT4 = BN / 64;
+    constexpr int A_INST = A_TILE / (1024 * NW), B_INST = B_TILE / (1024 * NW);
+    constexpr int NT4 = BN / WNG / 32;
+    static_assert(A_INST >= 1 && B_INST >= 1 && NT4 >= 1, "tile too small for this many waves");
     constexpr int BROWB = BN * 2;            // bytes per gathered fc2^T row slice
     constexpr int BCPR = BN / 8;             // 16-byte chunks per row
     constexpr int BRPI = 1024 / BROWB;       // rows per DMA instruction (2 for BN=256, 4 for BN=128)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WNG, wn = w % WNG;
 
     // all column tiles of fc2^T are live (N2 is dense); the map only reorders them for L2 reuse (see map_tile)
     const int G = p.M / BM;
@@ -548,14 +551,16 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
     // The gather keys of a tile are wave-uniform per DMA row, so they are fetched with SCALAR loads (lgkmcnt): the
     // vector-memory counter then only counts LDS-DMA and the counted vmcnt pipeline below stays intact.  The keys of
     // the tile issued NEXT iteration are fetched one iteration ahead so their latency hides behind the MFMAs.
-    constexpr int NKEY = B_INST * BRPI;          // keys per wave per tile (16)
+    constexpr int NKEY = B_INST * BRPI;          // keys per wave per tile (8): consecutive entries of the index list
+    static_assert(NKEY % 4 == 0, "a wave's keys are fetched as whole s_load_dwordx4/x8");
     int keys[NKEY];
     auto load_keys = [&](int kb) {
+        // counts are multiples of 8 and so is the block start: the block is live or dead as a whole, which lets the
+        // compiler fetch it with ONE wide scalar load instead of NKEY single ones
+        const int base = kb * BK + w * NKEY;
+        const int32_t *kp = idxg + __builtin_amdgcn_readfirstlane(base < cnt ? base : 0);
 #pragma unroll
-        for (int j = 0; j < NKEY; ++j) {
-            const int k = kb * BK + w * NKEY + j;
-            keys[j] = idxg[__builtin_amdgcn_readfirstlane(k < cnt ? k : 0)];  // s_load_dword
-        }
+        for (int j = 0; j < NKEY; ++j) keys[j] = kp[j];
     };
     const int rsel = lane / BCPR;                  // which of the instruction's BRPI rows this lane stages
     auto issue = [&](int kb, int buf) {
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
             for (int n4 = 0; n4 < NT4; ++n4) {
                 // lane group grp: n half = grp&1, k half = grp>>1; lane li addresses block row li>>2, cols (li&3)*4
                 const int row = kk * 16 + (grp >> 1) * 8 + (li >> 2);
-                const int chunk = (wn * (BN / 16) + n4 * 4 + (grp & 1) * 2 + ((li & 3) >> 1)) ^ ((row & 3) << 2);
+                const int chunk = (wn * (BN / WNG / 8) + n4 * 4 + (grp & 1) * 2 + ((li & 3) >> 1)) ^ ((row & 3) << 2);
                 const unsigned char *ba = Bt + row * BROWB + chunk * 16 + (li & 1) * 8;
                 const s16x4 lo = lds_read_tr16_b64(ba);
                 const s16x4 hi = lds_read_tr16_b64(ba + 4 * BROWB);
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(256, WPS) void mm2_kernel(const Mm2Params p) {
         for (int n4 = 0; n4 < NT4; ++n4) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const int n = n0 + wn * (BN / 2) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
+                const int n = n0 + wn * (BN / WNG) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
                 if (n >= p.N2) continue;
                 const u32x2 old = *(const u32x2 *)(crow + n);
                 const float a0 = round_bf16(acc[n4][mt][q4 * 4 + 0]), a1 = round_bf16(acc[n4][mt][q4 * 4 + 1]);
@@ -736,10 +741,10 @@ int launch_scatter_add(const void *packed, void *unpacked, const int32_t *indice
     return CHIPMUNK_OK;
 }
 
-template <int BN, int BK, int NST, int WPS>
+template <int BN, int BK, int NST, int WPS, int NW = 4>
 int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
     constexpr int LDS = NST * (BM * BK * 2 + BK * BN * 2);
-    auto kern = mm2_kernel<BN, BK, NST, WPS>;
+    auto kern = mm2_kernel<BN, BK, NST, WPS, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -749,7 +754,7 @@ int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
     p.NT = (p.N2 + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm2_nr") > 0 ? chipmunk_get_option("mm2_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
-    hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(NW * 64), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -768,6 +773,10 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
         case 7: return launch_mm2_variant<128, 32, 3, 3>(p, s);
         case 8: return launch_mm2_variant<256, 32, 3, 3>(p, s);
         case 9: return launch_mm2_variant<256, 64, 2, 2>(p, s);
+        case 10: return launch_mm2_variant<256, 64, 3, 1, 8>(p, s);
+        case 11: return launch_mm2_variant<256, 64, 2, 1, 8>(p, s);
+        case 12: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
+        case 13: return launch_mm2_variant<256, 32, 4, 1, 8>(p, s);
         default: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // measured best on FLUX shapes (profiles/r01_*)
     }
 }

@@ -103,9 +103,19 @@ def test_scatter_add(dev, M, F, counts):
     assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "scatter_add must be bit-exact"
 
 
+@pytest.mark.parametrize("variant", [0, 10, 12])  # 0: 4 waves, 128x256 tile, k step 32; 10/12: the 8-wave shapes
 @pytest.mark.parametrize("M,F,N2,counts", [(256, 512, 256, [64, 192]), (384, 1024, 384, [512, 8, 328]),
                                            (128, 512, 768, [512])])
-def test_mm2_and_scatter_add(dev, M, F, N2, counts):
+def test_mm2_and_scatter_add(dev, M, F, N2, counts, variant):
+    from chipmunk_amd import _native
+    _native.set_option("mm2_variant", variant)
+    try:
+        _mm2_and_scatter_add(dev, M, F, N2, counts)
+    finally:
+        _native.set_option("mm2_variant", 0)
+
+
+def _mm2_and_scatter_add(dev, M, F, N2, counts):
     packed = randn_bf16(M, F, seed=21, scale=0.2)
     # columns past the count hold garbage in the real pipeline (torch.empty): make sure they are never read
     for g, n in enumerate(counts):
