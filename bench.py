@@ -145,6 +145,10 @@ def build_flux(dev, n_layers, timer):
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # stdout carries exactly one JSON line
         cfg.load_from_file(os.path.join(ROOT, "configs", "flux_c2.yml"))
+    for item in filter(None, os.environ.get("BENCH_CFG", "").split(",")):   # A/B experiments: "mlp.fused_scatter=false"
+        key, _, val = item.partition("=")
+        sec, _, name = key.partition(".")
+        cfg.GLOBAL_CONFIG[sec][name] = {"true": True, "false": False}.get(val.lower(), val)
     # event brackets around the three sparse-step kernels
     mlp_ops.mm1 = timer.wrap("csp_mlp_mm1", mlp_ops.mm1, _mm1_work)
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, _mm2_work)

@@ -30,6 +30,12 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.chipmunk_last_error.restype = ctypes.c_char_p
         _lib.chipmunk_abi_version.restype = ctypes.c_int
+        # A/B experiments without code edits: CHIPMUNK_AMD_OPTIONS="mm2_variant=12,mm1_nr=8" (tuning knobs only;
+        # unknown names raise)
+        for item in filter(None, os.environ.get("CHIPMUNK_AMD_OPTIONS", "").split(",")):
+            name, _, val = item.partition("=")
+            if _lib.chipmunk_set_option(name.strip().encode(), int(val)) != 0:
+                raise ValueError(f"CHIPMUNK_AMD_OPTIONS: {_lib.chipmunk_last_error().decode()}")
     return _lib
 
 

@@ -777,7 +777,10 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
         case 11: return launch_mm2_variant<256, 64, 2, 1, 8>(p, s);
         case 12: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
         case 13: return launch_mm2_variant<256, 32, 4, 1, 8>(p, s);
-        default: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // measured best on FLUX shapes (profiles/r01_*)
+        case 14: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // the 4-wave form of the default
+        // 8 waves (2 x 4, 64 x 64 per wave, 4 waves per SIMD) x 2 workgroups per CU: equal to the 4-wave form in
+        // isolation, 2 % faster inside the bench loop (A/B on one box: 170.5 -> 167.3 us, twice)
+        default: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
     }
 }
 

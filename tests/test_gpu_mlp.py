@@ -103,7 +103,7 @@ def test_scatter_add(dev, M, F, counts):
     assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "scatter_add must be bit-exact"
 
 
-@pytest.mark.parametrize("variant", [0, 10, 12])  # 0: 4 waves, 128x256 tile, k step 32; 10/12: the 8-wave shapes
+@pytest.mark.parametrize("variant", [0, 10, 14])  # 0: shipped (8 waves, k step 32); 10: 8 waves, k step 64; 14: 4 waves
 @pytest.mark.parametrize("M,F,N2,counts", [(256, 512, 256, [64, 192]), (384, 1024, 384, [512, 8, 328]),
                                            (128, 512, 768, [512])])
 def test_mm2_and_scatter_add(dev, M, F, N2, counts, variant):
