@@ -488,6 +488,200 @@ int launch_m2i(const void *mask, int32_t *indices, int32_t *counts, int64_t rows
     return CHIPMUNK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ top-k -> mask
+// SURVEY 8f rank 1, second half: the reference's `random_and_topk` (src/chipmunk/modules/attn.py:76-82)
+//     mask = randint(0,100) == 0;  mask.scatter_(-1, cs.topk(k).indices, True);  mask = (mask * groups) | static
+// as ONE pass over the column sums instead of randint + topk + scatter + two element-wise kernels on a [H, G, N] bool
+// tensor (N = 119 056: 24.7 ms -> see DESIGN.md).
+// One 1024-thread workgroup per (head, query group) row.  The row's bf16 column sums are loaded ONCE into registers as
+// order-preserving 16-bit keys (4 consecutive columns per thread per step, KPT/2 packed VGPRs), the k-th largest key is
+// found by 16 rounds of bitwise bisection on block-wide counts (no sort, no histogram: the keys of one row sit in two or
+// three exponent bins, a histogram's atomics would serialise), ties at the threshold are handed out in thread order,
+// and the final mask bytes are written straight from the registers, 4 per thread per store.
+struct TopkMaskParams {
+    const uint16_t *cs;      // [rows, cs_stride] bf16
+    const uint8_t *stat;     // optional static mask, row r -> stat + (r % stat_rows) * stat_stride
+    const uint8_t *groups;   // optional per-row flag (the random / top-k part only applies where it is set)
+    uint8_t *mask;           // [rows, n] bool bytes, fully overwritten
+    int64_t cs_stride, stat_stride;
+    int rows, n, k, stat_rows;
+    float random_amount;
+};
+
+__device__ __forceinline__ uint32_t bf16_key(uint32_t u) {  // monotone bf16 bits -> u16 (larger value = larger key)
+    return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+}
+
+template <int KPT, bool ALIGNED>  // keys per thread (multiple of 4); the row must have n <= 1024 * KPT columns.
+// ALIGNED: n % 4 == 0 and every row of cs / static mask / mask starts on an 8 / 4 / 4-byte boundary, so each thread
+// step is one 8-byte load, one 4-byte load and one 4-byte store; the generic form goes element by element.
+__global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p) {
+    constexpr int NV = KPT / 4;  // 4-column steps per thread
+    __shared__ int wave_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = blockIdx.x;
+    const uint16_t *x = p.cs + (int64_t)row * p.cs_stride;
+    const int n = p.n;
+    const uint32_t lane_off8 = 8u * (uint32_t)tid;    // byte offset of this thread's 4 bf16 inside a 4096-column step
+    const uint32_t lane_off4 = 4u * (uint32_t)tid;    // ... of its 4 mask bytes
+    // columns 4*tid + 4096*j .. +3; columns past n read as bf16 bits 0xffff = key 0, below every real key
+    uint32_t key[NV][2];
+    constexpr int LB = NV % 10 == 0 ? 10 : (NV % 8 == 0 ? 8 : (NV % 6 == 0 ? 6 : 4));  // loads in flight per batch
+    static_assert(NV % LB == 0, "NV must split into whole load batches");
+#pragma unroll
+    for (int j0 = 0; j0 < NV; j0 += LB) {
+        // batch of LB loads, then their conversion: bounds the live raw values (all NV at once would spill)
+        uint32_t raw[LB][2];
+#pragma unroll
+        for (int jj = 0; jj < LB; ++jj) {
+            const int c = 4 * tid + 4096 * (j0 + jj);
+            uint32_t v0 = 0xffffffffu, v1 = 0xffffffffu;
+            if constexpr (ALIGNED) {
+                if (c < n) {
+                    // wave-uniform base + one shared 32-bit lane offset: the saddr form, no 64-bit address per step
+                    const u32x2 v = *(const u32x2 *)((const unsigned char *)(x + 4096 * (j0 + jj)) + lane_off8);
+                    v0 = v[0], v1 = v[1];
+                }
+            } else if (c < n) {
+                v0 = v1 = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t u = c + e < n ? x[c + e] : 0xffffu;
+                    if (e < 2) v0 |= u << (16 * e);
+                    else v1 |= u << (16 * (e - 2));
+                }
+            }
+            raw[jj][0] = v0, raw[jj][1] = v1;
+        }
+#pragma unroll
+        for (int jj = 0; jj < LB; ++jj) {
+            key[j0 + jj][0] = bf16_key(raw[jj][0] & 0xffffu) | (bf16_key(raw[jj][0] >> 16) << 16);
+            key[j0 + jj][1] = bf16_key(raw[jj][1] & 0xffffu) | (bf16_key(raw[jj][1] >> 16) << 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto block_count = [&](int mine) {  // sum over the 1024 threads, broadcast
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0) wave_cnt[w] = mine;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += wave_cnt[i];
+        __syncthreads();
+        return t;
+    };
+    const bool active = p.groups == nullptr || p.groups[row] != 0;
+    const int k = p.k < n ? p.k : n;
+    uint32_t thr = 0x10000u;  // keep nothing
+    int ties_to_take = 0;
+    if (active && k > 0) {
+        // ---- largest T with #{key >= T} >= k, most significant bit first
+        uint32_t res = 0;
+        for (int bit = 15; bit >= 0; --bit) {
+            const uint32_t cand = res | (1u << bit);
+            const uint32_t off = 0x10000u - cand;  // (half + off) >> 16 == (half >= cand)
+            int mine = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t kw = key[j][h];
+                    // opaque to the optimiser: otherwise it hoists the unpacked halves of all NV*2 words out of the
+                    // 16 rounds (4 * NV more live registers)
+                    asm volatile("" : "+v"(kw));
+                    mine += (int)(((kw & 0xffffu) + off) >> 16) + (int)(((kw >> 16) + off) >> 16);
+                }
+            if (block_count(mine) >= k) res = cand;
+        }
+        thr = res;
+        int gt = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t kw = key[j][h];
+                asm volatile("" : "+v"(kw));
+                gt += ((kw & 0xffffu) > thr ? 1 : 0) + ((kw >> 16) > thr ? 1 : 0);
+            }
+        ties_to_take = k - block_count(gt);  // >= 1 by construction of thr
+    }
+    // ---- ties at the threshold go to the lowest thread ids (torch.topk leaves the choice among equals unspecified)
+    int my_ties = 0;
+    if (ties_to_take > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t kw = key[j][h];
+                asm volatile("" : "+v"(kw));
+                my_ties += ((kw & 0xffffu) == thr ? 1 : 0) + ((kw >> 16) == thr ? 1 : 0);
+            }
+    }
+    int tie_budget = 0;
+    {
+        int incl = my_ties;  // inclusive scan over the block: wave scan, then the 16 wave totals
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_cnt[w] = incl;
+        __syncthreads();
+        int before = incl - my_ties;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) before += i < w ? wave_cnt[i] : 0;
+        __syncthreads();
+        tie_budget = ties_to_take - before;  // how many of MY ties are taken (clamped below)
+    }
+    // ---- write the mask: (top-k | random) & group | static.  ROLLED loop that re-reads the row's column sums (the
+    //      workgroup's own row: L2 / Infinity-Cache hits) instead of taking them from the key registers: an unrolled
+    //      register-fed output loop needs ~60 more live registers than the selection and spilled at 30 steps per thread.
+    uint8_t *out = p.mask + (int64_t)row * n;
+    const uint8_t *st = p.stat ? p.stat + (int64_t)(row % p.stat_rows) * p.stat_stride : nullptr;
+    const bool rnd = active && p.random_amount > 0.f;
+    const int nsteps = (n + 4095) / 4096;
+#pragma unroll 2
+    for (int j = 0; j < nsteps; ++j) {
+        const int c = 4 * tid + 4096 * j;
+        if (c >= n) break;
+        uint32_t v0 = 0, v1 = 0, sb = 0;
+        if constexpr (ALIGNED) {
+            const u32x2 v = *(const u32x2 *)(x + c);
+            v0 = v[0], v1 = v[1];
+            if (st) sb = *(const uint32_t *)(st + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t u = c + e < n ? x[c + e] : 0xffffu;
+                if (e < 2) v0 |= u << (16 * e);
+                else v1 |= u << (16 * (e - 2));
+                if (st && c + e < n) sb |= (uint32_t)st[c + e] << (8 * e);
+            }
+        }
+        uint32_t bytes = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t kv = bf16_key(((e < 2 ? v0 : v1) >> (16 * (e & 1))) & 0xffffu);
+            bool keep = kv > thr;                      // thr = 0x10000 when the row is inactive or k = 0
+            const bool tie = kv == thr && tie_budget > 0 && c + e < n;
+            tie_budget -= tie ? 1 : 0;
+            keep = keep || tie;
+            if (rnd && !keep) keep = hash_uniform(row, c + e) < p.random_amount;
+            keep = keep || ((sb >> (8 * e)) & 0xffu) != 0;
+            bytes |= (keep ? 1u : 0u) << (8 * e);
+        }
+        if constexpr (ALIGNED) {
+            *(uint32_t *)(out + c) = bytes;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < n) out[c + e] = (uint8_t)(bytes >> (8 * e));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int chipmunk_mask_to_indices(const void *mask, int32_t *indices, int32_t *counts, int64_t rows, int n,
@@ -592,6 +786,34 @@ extern "C" int chipmunk_transpose16(const void *src, void *dst, int B, int R, in
     CM_CHECK((C & 7) == 0 || true, "unreachable");
     hipLaunchKernelGGL(transpose16_kernel, dim3((C + 63) / 64, (R + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)src, (uint16_t *)dst, R, C);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void *static_mask, int64_t static_stride,
+                                  int static_rows, const void *group_flags, void *mask, int rows, int n, int k,
+                                  double random_amount, void *stream) {
+    CM_CHECK(cs && mask, "topk_mask: null pointer");
+    CM_CHECK(rows >= 0 && n > 0 && k >= 0, "topk_mask: bad sizes (rows=%d n=%d k=%d)", rows, n, k);
+    CM_CHECK(cs_stride >= n, "topk_mask: cs row stride %lld < n %d", (long long)cs_stride, n);
+    CM_CHECK(n <= 1024 * 120, "topk_mask: rows of more than 122880 columns are not supported (got %d)", n);
+    CM_CHECK(!static_mask || (static_rows > 0 && static_stride >= n), "topk_mask: bad static mask geometry");
+    CM_CHECK(random_amount >= 0.0 && random_amount <= 1.0, "topk_mask: random_amount must be in [0,1]");
+    if (rows == 0) return CHIPMUNK_OK;
+    TopkMaskParams p = {(const uint16_t *)cs, (const uint8_t *)static_mask, (const uint8_t *)group_flags, (uint8_t *)mask,
+                        cs_stride, static_stride, rows, n, k, static_mask ? static_rows : 1, (float)random_amount};
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned = n % 4 == 0 && (((uintptr_t)cs) & 7) == 0 && (cs_stride * 2) % 8 == 0 && (((uintptr_t)mask) & 3) == 0 &&
+                         (!static_mask || ((((uintptr_t)static_mask) & 3) == 0 && static_stride % 4 == 0));
+#define LAUNCH_TM(KPT)                                                                                       \
+    do {                                                                                                     \
+        if (aligned) hipLaunchKernelGGL((topk_mask_kernel<KPT, true>), dim3(rows), dim3(1024), 0, s, p);     \
+        else hipLaunchKernelGGL((topk_mask_kernel<KPT, false>), dim3(rows), dim3(1024), 0, s, p);            \
+    } while (0)
+    if (n <= 1024 * 16) LAUNCH_TM(16);
+    else if (n <= 1024 * 48) LAUNCH_TM(48);
+    else LAUNCH_TM(120);
+#undef LAUNCH_TM
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

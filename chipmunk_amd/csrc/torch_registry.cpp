@@ -442,6 +442,43 @@ std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef 
     return {indices, counts};
 }
 
+// addition: randint + topk + scatter_ + the two mask combines of modules/attn.py:76-82 in one kernel
+at::Tensor topk_mask(at::Tensor cs, int64_t k, double random_amount, const c10::optional<at::Tensor> &groups,
+                     const c10::optional<at::Tensor> &static_mask) {
+    CHECK_DEV(cs); CHECK_BF16(cs);
+    TORCH_CHECK(cs.dim() == 4 && cs.stride(3) == 1, "cs must be [B, H, G, N] with a contiguous last dim");
+    const int64_t B = cs.size(0), H = cs.size(1), G = cs.size(2), N = cs.size(3);
+    // rows must be addressable with one stride: collapse (B, H, G) or copy
+    if (!(cs.stride(1) == G * cs.stride(2) && (B == 1 || cs.stride(0) == H * cs.stride(1)))) cs = cs.contiguous();
+    const int64_t rows = B * H * G;
+    c10::DeviceGuard guard(cs.device());
+    at::Tensor mask = at::empty({B, H, G, N}, cs.options().dtype(at::kBool));
+    const void *st = nullptr, *gf = nullptr;
+    int64_t st_stride = 0, st_rows = 1;
+    at::Tensor stc, gfc;
+    if (static_mask.has_value() && static_mask->defined()) {
+        stc = *static_mask;
+        CHECK_DEV(stc);
+        TORCH_CHECK(stc.scalar_type() == at::kBool && stc.dim() == 4 && stc.size(3) == N && stc.size(2) == G &&
+                    stc.size(1) == H && (stc.size(0) == 1 || stc.size(0) == B), "static_mask must be bool [1|B, H, G, N]");
+        if (!(stc.stride(3) == 1 && stc.stride(1) == G * stc.stride(2) && (stc.size(0) == 1 || stc.stride(0) == H * stc.stride(1))))
+            stc = stc.contiguous();
+        st = stc.data_ptr(), st_stride = stc.stride(2), st_rows = stc.size(0) * H * G;
+    }
+    if (groups.has_value() && groups->defined()) {
+        gfc = *groups;
+        CHECK_DEV(gfc);
+        TORCH_CHECK(gfc.scalar_type() == at::kBool && gfc.dim() == 4 && gfc.size(3) == 1 && gfc.size(2) == G &&
+                    gfc.size(1) == H && (gfc.size(0) == 1 || gfc.size(0) == B), "groups must be bool [1|B, H, G, 1]");
+        gfc = gfc.expand({B, H, G, 1}).contiguous();
+        gf = gfc.data_ptr();
+    }
+    check(chipmunk_topk_mask(cs.data_ptr(), cs.stride(2), st, st_stride, (int)st_rows, gf, mask.data_ptr(), (int)rows, (int)N,
+                             (int)k, random_amount, cur_stream(cs)),
+          "topk_mask");
+    return mask;
+}
+
 // reference src/chipmunk/ops/bitpack.py:4-69 as single kernels
 at::Tensor bitpack(at::Tensor mask) {
     TORCH_CHECK(mask.scalar_type() == at::kBool, "mask must be bool type");
@@ -490,6 +527,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("mask_to_sorted_indices(Tensor mask, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
+    m.def("topk_mask(Tensor cs, int k, float random_amount, Tensor? groups, Tensor? static_mask) -> Tensor");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -513,6 +551,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("topk_delta_indices", &topk_delta_indices);
     m.impl("packed_mask_to_indices", &packed_mask_to_indices);
     m.impl("mask_to_sorted_indices", &mask_to_sorted_indices);
+    m.impl("topk_mask", &topk_mask);
     m.impl("transpose_last2", &transpose_last2);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);

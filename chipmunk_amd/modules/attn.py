@@ -70,9 +70,14 @@ class SparseDiffAttn(nn.Module):
 
     def random_and_topk(self, cs: Tensor, topk: int) -> Tensor:
         """1% random keys + top-k column sums, limited to the groups that are sparse at all, plus the static mask."""
+        cfg = GLOBAL_CONFIG["attn"]
+        qg, n = cs.shape[-2], cs.shape[-1]
+        if cs.is_cuda and cfg.get("fused_topk_mask", True) and cs.dtype == torch.bfloat16 and n <= 122880:
+            # one kernel for the whole chain below (the random 1 % comes from a counter-based hash, not torch's RNG)
+            return ops.topk_mask(cs, topk, 0.01, singleton_video_query_groups[..., :qg, :],
+                                 singleton_static_mask[..., :qg, :n])
         mask = torch.randint(0, 100, cs.shape, device=cs.device, dtype=torch.uint8) == 0
         mask.scatter_(-1, cs.topk(k=topk, dim=-1).indices, True)
-        qg, n = cs.shape[-2], cs.shape[-1]
         # (mask * groups) | static of the reference (modules/attn.py:76-82) as in-place logical ops on the fresh mask: same
         # booleans, no bool x bool product kernel and no two 1.8 GB temporaries at HunyuanVideo size (16 -> 3 ms)
         mask.logical_and_(singleton_video_query_groups[..., :qg, :n])

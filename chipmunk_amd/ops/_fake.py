@@ -40,6 +40,10 @@ def _register():
         pad_n = (n + pad_to_multiple_of - 1) // pad_to_multiple_of * pad_to_multiple_of
         return [packed.new_empty((b, h, m, pad_n), dtype=torch.int32), packed.new_empty((b, h, m), dtype=torch.int32)]
 
+    @lib.register_fake("chipmunk::topk_mask")
+    def _(cs, k, random_amount, groups, static_mask):
+        return cs.new_empty(cs.shape, dtype=torch.bool)
+
     @lib.register_fake("chipmunk::bitpack")
     def _(mask):
         return mask.new_empty(((mask.numel() + 7) // 8,), dtype=torch.uint8)

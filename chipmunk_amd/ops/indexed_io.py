@@ -1,7 +1,7 @@
 """Indexed-IO op wrappers (mirror of reference ``src/chipmunk/ops/indexed_io.py:1-37``)."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -36,3 +36,12 @@ def mask_to_sorted_indices(mask: torch.Tensor, shape: Sequence[int], multiple_of
     """Same kept set / counts / padding as ``mask_to_indices`` (``mask`` bool) or ``packed_mask_to_indices`` (``mask``
     uint8 bit-packed, ``shape`` = original mask shape) with ASCENDING columns: sequential DRAM pages for the K/V gather."""
     return torch.ops.chipmunk.mask_to_sorted_indices(mask, list(shape), multiple_of, pad_to_multiple_of)
+
+
+def topk_mask(cs: torch.Tensor, k: int, random_amount: float = 0.0, groups: Optional[torch.Tensor] = None,
+              static_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``((top-k of cs | random) & groups) | static_mask`` as one kernel: the reference's ``random_and_topk``
+    (``modules/attn.py:76-82``: randint + topk + scatter_ + two mask combines).  Exactly ``k`` columns per active row
+    come from the top-k part (ties at the k-th value broken deterministically); the random part is a counter-based
+    hash, so only ``random_amount = 0`` is comparable bit for bit with the torch chain."""
+    return torch.ops.chipmunk.topk_mask(cs, k, random_amount, groups, static_mask)

@@ -144,6 +144,18 @@ int chipmunk_topk_delta_indices(const void *activation, void *cache, int dtype, 
                                 int rows, int cols, double sparsity_amount, int multiple_of, double random_amount,
                                 void *stream);
 
+/* Fused mask construction of the attention mask-building step (reference
+ * src/chipmunk/modules/attn.py:76-82 `random_and_topk`):
+ *   mask[r, c] = ((c in topk_k(cs[r, :n])) | (u(r, c) < random_amount)) & group_flags[r]  |  static_mask[r % static_rows, c]
+ * cs [rows, cs_stride] bf16 column sums; static_mask (optional) bool bytes with row stride static_stride, broadcast over
+ * rows modulo static_rows; group_flags (optional) one byte per row; mask [rows, n] bool bytes, fully overwritten.
+ * Exactly k columns per active row come from the top-k part; ties at the k-th value are broken deterministically (the
+ * reference's torch.topk leaves that choice unspecified); u is a counter-based hash (RNG streams cannot match torch's
+ * randint), so results are comparable with the reference chain for random_amount = 0.  n <= 122 880. */
+int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void *static_mask, int64_t static_stride,
+                       int static_rows, const void *group_flags, void *mask, int rows, int n, int k,
+                       double random_amount, void *stream);
+
 /* Replaces chipmunk::mask_to_indices (reference csrc/indexed_io/mask_to_indices.cu:92-143; schema chipmunk.cpp:60).
  * mask [rows, n] bool bytes; indices [rows, pad_n] int32; counts [rows] int32.  Bit-exact order: True columns of
  * residue class t (mod 32) ascending for t = 0..31, then the first False columns ascending up to multiple_of. */

@@ -157,3 +157,51 @@ def test_mask_to_sorted_indices_same_set_ascending(dev, shape, density):
         pi, pc = chipmunk_amd.ops.mask_to_sorted_indices(packed, shp, 128, 192)
         live = torch.arange(si.shape[-1], device=dev)[None, None, None, :] < sc.clamp(max=shape[-1])[..., None]
         assert torch.equal(pc, sc) and torch.equal(pi[live], si[live])
+
+
+def _distinct_bf16_rows(rows, n, seed):
+    """rows x n bf16 values, all distinct within a row (positive normal bf16 bit patterns, permuted): no ties."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.arange(0x3000, 0x3000 + n, dtype=torch.int32)  # 0x3000.. : positive normals well below inf
+    assert 0x3000 + n < 0x7f80
+    out = torch.stack([base[torch.randperm(n, generator=g)] for _ in range(rows)])
+    return out.to(torch.int16).view(torch.bfloat16)
+
+
+@pytest.mark.parametrize("H,G,n,k", [(2, 3, 4352, 672), (1, 2, 20000, 1000), (1, 2, 10003, 517)])
+def test_topk_mask_equals_reference_chain_without_ties(dev, H, G, n, k):
+    """topk_mask with random_amount = 0 == the reference's `random_and_topk` chain (modules/attn.py:76-82) minus its
+    randint: scatter_(topk) & groups | static -- exact on tie-free rows (aligned and unaligned row lengths)."""
+    cs = _distinct_bf16_rows(H * G, n, seed=3).view(1, H, G, n).to(dev)
+    g = torch.Generator().manual_seed(4)
+    static = (torch.rand(1, H, G, n, generator=g) < 0.02).to(dev)
+    groups = torch.tensor([True, False, True, True, False, True][:H * G]).view(1, H, G, 1).to(dev)
+    ref = torch.zeros(1, H, G, n, dtype=torch.bool, device=dev)
+    ref.scatter_(-1, cs.float().topk(k=k, dim=-1).indices, True)
+    ref = (ref & groups) | static
+    out = torch.ops.chipmunk.topk_mask(cs, k, 0.0, groups, static)
+    assert out.dtype == torch.bool and out.shape == ref.shape
+    assert torch.equal(out, ref)
+    # no optional inputs
+    out2 = torch.ops.chipmunk.topk_mask(cs, k, 0.0, None, None)
+    ref2 = torch.zeros_like(ref).scatter_(-1, cs.float().topk(k=k, dim=-1).indices, True)
+    assert torch.equal(out2, ref2)
+
+
+def test_topk_mask_ties_and_random(dev):
+    """With ties at the k-th value exactly k columns are taken, everything above the threshold is kept and nothing below;
+    the random part adds about random_amount of the remaining columns, only in active groups."""
+    H, G, n, k = 2, 2, 8192, 1000
+    g = torch.Generator().manual_seed(5)
+    cs = (torch.randint(0, 40, (1, H, G, n), generator=g).float() / 8).to(torch.bfloat16).to(dev)  # heavy ties
+    out = torch.ops.chipmunk.topk_mask(cs, k, 0.0, None, None)
+    assert (out.sum(-1) == k).all()
+    v = cs.float()
+    kth = v.topk(k, dim=-1).values[..., -1:]
+    assert out[v > kth].all() and not out[v < kth].any()
+    groups = torch.tensor([True, False, True, False]).view(1, H, G, 1).to(dev)
+    out_r = torch.ops.chipmunk.topk_mask(cs, k, 0.01, groups, None)
+    extra = out_r.sum(-1) - k * groups.squeeze(-1).long()
+    assert (extra[~groups.squeeze(-1)] == 0).all()
+    assert ((extra[groups.squeeze(-1)] > 30) & (extra[groups.squeeze(-1)] < 130)).all()  # ~1 % of 7192
+    assert (out_r | ~out)[groups.expand_as(out)].all()  # the random part only adds
