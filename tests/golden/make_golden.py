@@ -253,12 +253,36 @@ def module_runs(ref):
     return out
 
 
+def fp8_scales(ref):
+    """F8Linear scale arithmetic of the reference (modules/mlp_fp8.py:169-221) on fixed tensors --
+    weight quantisation, and the input scale over 14 calls (12 calibration trials, the freezing call, one frozen)."""
+    f8 = importlib.import_module("chipmunk.modules.mlp_fp8")
+    out = {}
+    for tag, in_dt in (("e4m3", torch.float8_e4m3fn), ("e5m2", torch.float8_e5m2)):
+        lin = torch.nn.Linear(48, 32, dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(_seeded((32, 48), 301, 0.7))
+            lin.bias.copy_(_seeded((32,), 302, 0.1))
+        q = f8.F8Linear.from_linear(lin, float8_dtype=torch.float8_e4m3fn, input_float8_dtype=in_dt)
+        rec = {"weight_bits": q.weight.data.view(torch.uint8).clone(), "scale": q.scale.clone(),
+               "scale_reciprocal": q.scale_reciprocal.clone(), "calls": []}
+        for i in range(14):
+            x = _seeded((5, 48), 400 + i, 0.5 + 0.37 * ((i * 7) % 5))
+            xq = q.quantize_input(x)
+            rec["calls"].append({"bits": xq.view(torch.uint8).clone(), "input_scale": q.input_scale.clone(),
+                                 "input_scale_reciprocal": q.input_scale_reciprocal.clone(),
+                                 "initialized": bool(q.input_scale_initialized), "trial_index": int(q.trial_index)})
+        out[tag] = rec
+    return out
+
+
 def main():
     ref = import_reference()
     torch.save(layer_counter_traces(ref), os.path.join(HERE, "layer_counter.pt"))
     torch.save(config_merges(ref), os.path.join(HERE, "config_merge.pt"))
     torch.save(patch_voxel_bitpack(ref), os.path.join(HERE, "layout_ops.pt"))
     torch.save(module_runs(ref), os.path.join(HERE, "module_runs.pt"))
+    torch.save(fp8_scales(ref), os.path.join(HERE, "fp8_scales.pt"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -132,3 +132,29 @@ def test_bitpack_cpu_path_and_oracle_agree():
     assert torch.equal(packed, gold["bitpack_out"])
     assert torch.equal(oracle.bitpack(gold["bitpack_in"])[0], gold["bitpack_out"])
     assert torch.equal(bitunpack(packed, shape), gold["bitpack_in"])
+
+
+@pytest.mark.parametrize("tag,in_dt", [("e4m3", torch.float8_e4m3fn), ("e5m2", torch.float8_e5m2)])
+def test_f8linear_scale_arithmetic_matches_reference(tag, in_dt):
+    """weight quantisation and the 12-trial input-scale calibration of the reference's F8Linear
+    (modules/mlp_fp8.py:169-221), bit for bit, from tests/golden/fp8_scales.pt (generated by importing the reference)."""
+    from chipmunk_amd.modules.mlp_fp8 import F8Linear
+
+    def seeded(shape, seed, scale=1.0):
+        return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(torch.bfloat16)
+
+    gold = _load("fp8_scales.pt")[tag]
+    lin = torch.nn.Linear(48, 32, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(seeded((32, 48), 301, 0.7))
+        lin.bias.copy_(seeded((32,), 302, 0.1))
+    q = F8Linear.from_linear(lin, float8_dtype=torch.float8_e4m3fn, input_float8_dtype=in_dt)
+    assert torch.equal(q.weight.data.view(torch.uint8), gold["weight_bits"])
+    assert torch.equal(q.scale, gold["scale"]) and torch.equal(q.scale_reciprocal, gold["scale_reciprocal"])
+    for i, want in enumerate(gold["calls"]):
+        x = seeded((5, 48), 400 + i, 0.5 + 0.37 * ((i * 7) % 5))
+        xq = q.quantize_input(x)
+        assert torch.equal(xq.view(torch.uint8), want["bits"]), f"call {i}"
+        assert torch.equal(q.input_scale, want["input_scale"]), f"call {i}"
+        assert torch.equal(q.input_scale_reciprocal, want["input_scale_reciprocal"]), f"call {i}"
+        assert bool(q.input_scale_initialized) == want["initialized"] and int(q.trial_index) == want["trial_index"], f"call {i}"
