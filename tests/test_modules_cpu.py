@@ -163,3 +163,37 @@ def test_fused_packed_path_gives_same_result_on_cpu_tensors(cpu_chipmunk):
         torch.manual_seed(step)
         out = layer(q, k, v)
         assert out.shape == q.shape and torch.isfinite(out.float()).all()
+
+
+def test_step_cache_follows_reference_schedule_and_counter(fresh_config):
+    """StepCache (reference: inlined in examples/hunyuan/.../models.py:732-741,834-835 and examples/wan/.../model.py:
+    580-593,628-630): skipped steps return the last computed state of the same invocation and advance the shared counter
+    by exactly one model invocation; computed steps leave the counter to the modules."""
+    from chipmunk_amd.util import GLOBAL_CONFIG, LayerCounter, StepCache
+    GLOBAL_CONFIG["steps"] = 12
+    GLOBAL_CONFIG["step_caching"] = {"is_enabled": True, "skip_step_schedule": {3, 4, 7}}
+    for n_inv in (1, 2):
+        GLOBAL_CONFIG["num_model_invocations_per_inference_step"] = n_inv
+        counter = LayerCounter(num_layers=3, num_sparse_submodules_per_layer=1)
+        cache = StepCache(counter)
+        seen = []
+        for step in range(9):
+            for inv in range(n_inv):
+                assert counter.cur_inference_step == step and counter.cur_model_invocation_per_step == inv
+                if cache.should_skip(step):
+                    seen.append((step, inv, "skip", float(cache.skip()[0])))
+                else:
+                    for _ in range(3):          # the three blocks tick the odometer themselves
+                        counter.increment()
+                    cache.store(torch.full((2,), 10.0 * step + inv))
+                    seen.append((step, inv, "run", 10.0 * step + inv))
+        for step, inv, kind, val in seen:
+            if kind == "skip":
+                last_run = max(s for s, i, k, _ in seen if k == "run" and i == inv and s < step)
+                assert val == 10.0 * last_run + inv
+    GLOBAL_CONFIG["step_caching"]["is_enabled"] = False
+    assert not StepCache(counter).should_skip(3)
+    cache2 = StepCache(LayerCounter(1, 1))
+    GLOBAL_CONFIG["step_caching"]["is_enabled"] = True
+    with pytest.raises(RuntimeError):
+        cache2.skip()
