@@ -300,6 +300,10 @@ def main():
         torch.cuda.synchronize()
         dense_sps = args.dense_steps / (time.perf_counter() - t0)
 
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                      # nobody tears the communicator down while a peer is still timing
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = world * args.steps / elapsed
