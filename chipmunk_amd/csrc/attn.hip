@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
     const int row0 = g * QG + w * QW;
+    const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
+    const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;  // row strides in bytes
 
     // ---- Q^T fragments (B operand): lane = query column li, k = lg*8..lg*8+7 of each 32-wide d step
     bf16x8 qf[3][4];
@@ -167,10 +169,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 key = GATHER ? key_ring[(T % KRING) * 64 + r] : pos;
                 key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);  // memory safety for malformed indices
             }
-            const uint16_t *ksrc = kbase + (int64_t)key * p.ks[2] + ((li ^ (r & 15)) << 3);
-            const uint16_t *vsrc = vbase + (int64_t)key * p.vs[2] + ((li ^ ((r & 7) << 1)) << 3);
-            glds16(ksrc, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
-            if constexpr (!CSONLY) glds16(vsrc, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
+            // buffer-form DMA: per-(b, h) SGPR resource + 32-bit lane offset (row * stride + swizzled 16-byte chunk)
+            const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
+            const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
+            blds16(krsrc, koff, 0, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
+            if constexpr (!CSONLY) blds16(vrsrc, voff, 0, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
         }
     };
 
@@ -526,6 +529,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     }
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
+    CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
+             "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
     pp.xcd_chunks = chipmunk_get_option("attn_xcd_chunks");
