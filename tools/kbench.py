@@ -180,6 +180,24 @@ def bench_io(which):
         counts = torch.empty(1, 34, dtype=torch.int32, device=dev)
         ms = timeit(lambda: torch.ops.chipmunk.topk_indices(act, inds, counts, 0.7, 256, 0.05))
         print(f"topk_indices [1,34,12288]: {ms*1e3:8.1f} us")
+    elif which == "topkd":
+        # the fused |b - cache| -> top-k -> copy kernel of the sparse MLP step, KB_LAYERS sets of (b, cache) rotating
+        L = int(os.environ.get("KB_LAYERS", "1"))
+        sets = []
+        for _ in range(L):
+            b = torch.randn(1, 34, 12288, device=dev, generator=g).to(torch.bfloat16)
+            c = (b.float() + 0.3 * torch.randn(1, 34, 12288, device=dev, generator=g)).to(torch.bfloat16)
+            sets.append((b, c, torch.empty(1, 34, 12288, dtype=torch.int32, device=dev),
+                         torch.empty(1, 34, dtype=torch.int32, device=dev)))
+        # evict between launches like the real loop does: a 300 MB memset-sized touch is too slow; rotate instead
+        st = {"i": 0}
+
+        def run():
+            st["i"] = (st["i"] + 1) % L
+            b, c, inds, counts = sets[st["i"]]
+            torch.ops.chipmunk.topk_delta_indices(b, c, inds, counts, 0.7, 256, 0.05)
+        ms = timeit(run)
+        print(f"topk_delta_indices [1,34,12288] layers={L}: {ms*1e3:8.1f} us")
     elif which == "m2i":
         H, G, N = 24, 621, 119232
         mask = torch.rand(1, H, G, N, device=dev, generator=g) < 0.06
@@ -216,7 +234,7 @@ def main():
     for w in args.what:
         if w in ("mm1", "mm1s", "mm2", "scatter"):
             bench_mlp(w, variants)
-        elif w in ("topk", "m2i", "copy"):
+        elif w in ("topk", "topkd", "m2i", "copy"):
             bench_io(w)
         else:
             bench_attn(w, variants)
