@@ -657,23 +657,65 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
     }
     // ---- epilogue: lane owns row m = lane&31 of each tile and 4 consecutive n per accumulator quad
     //      C = bf16(acc) + C in bf16  (triton/csp_mlp_mm2.py:100-101)
+    constexpr bool STAGED = BM * BN * 2 <= NST * STAGE;
+    if constexpr (STAGED) {
+        // bf16(acc) goes through the (now free) ring as a row-major [128][BN] tile, 16-byte chunk c of row m stored at
+        // chunk c ^ (m & 31) (the 32 lanes of a store hit 32 rows at one column offset); the read-modify-write of C
+        // then runs as 16-byte accesses over whole BN*2-byte row segments instead of 8-byte accesses 32 rows apart.
+        constexpr int CPRO = BN / 8;  // 16-byte chunks per output row
+        __syncthreads();              // every wave is done reading the last operand stage
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = g * BM + wm * 64 + mt * 32 + (lane & 31);
-        uint16_t *crow = p.c + (int64_t)m * p.N2;
+        for (int mt = 0; mt < 2; ++mt) {
+            const int ml = wm * 64 + mt * 32 + (lane & 31);
 #pragma unroll
-        for (int n4 = 0; n4 < NT4; ++n4) {
+            for (int n4 = 0; n4 < NT4; ++n4) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int n = n0 + wn * (BN / WNG) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
-                if (n >= p.N2) continue;
-                const u32x2 old = *(const u32x2 *)(crow + n);
-                const float a0 = round_bf16(acc[n4][mt][q4 * 4 + 0]), a1 = round_bf16(acc[n4][mt][q4 * 4 + 1]);
-                const float a2 = round_bf16(acc[n4][mt][q4 * 4 + 2]), a3 = round_bf16(acc[n4][mt][q4 * 4 + 3]);
-                u32x2 out;
-                out[0] = pack_bf16x2(a0 + __uint_as_float(old[0] << 16), a1 + __uint_as_float(old[0] & 0xffff0000u));
-                out[1] = pack_bf16x2(a2 + __uint_as_float(old[1] << 16), a3 + __uint_as_float(old[1] & 0xffff0000u));
-                *(u32x2 *)(crow + n) = out;
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nl = wn * (BN / WNG) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
+                    u32x2 v;
+                    v[0] = pack_bf16x2(acc[n4][mt][q4 * 4 + 0], acc[n4][mt][q4 * 4 + 1]);
+                    v[1] = pack_bf16x2(acc[n4][mt][q4 * 4 + 2], acc[n4][mt][q4 * 4 + 3]);
+                    *(u32x2 *)(smem + ml * (BN * 2) + ((((nl >> 3) ^ (ml & (CPRO - 1) & 31)) << 4) | ((nl & 4) << 1))) = v;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int ITEMS = BM * CPRO / (NW * 64);  // 16-byte pieces per thread
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = it * (NW * 64) + tid;
+            const int r = item / CPRO, ch = item % CPRO;
+            const int n = n0 + ch * 8;
+            if (n >= p.N2) continue;  // N2 is a multiple of 8: a chunk is live or dead as a whole
+            const u32x4 a = *(const u32x4 *)(smem + r * (BN * 2) + ((ch ^ (r & (CPRO - 1) & 31)) << 4));
+            uint16_t *cp = p.c + (int64_t)(g * BM + r) * p.N2 + n;
+            const u32x4 old = *(const u32x4 *)cp;
+            u32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[e] = pack_bf16x2(__uint_as_float(a[e] << 16) + __uint_as_float(old[e] << 16),
+                                     __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(old[e] & 0xffff0000u));
+            *(u32x4 *)cp = out;
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = g * BM + wm * 64 + mt * 32 + (lane & 31);
+            uint16_t *crow = p.c + (int64_t)m * p.N2;
+#pragma unroll
+            for (int n4 = 0; n4 < NT4; ++n4) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n0 + wn * (BN / WNG) + n4 * 32 + q4 * 8 + (lane >> 5) * 4;
+                    if (n >= p.N2) continue;
+                    const u32x2 old = *(const u32x2 *)(crow + n);
+                    const float a0 = round_bf16(acc[n4][mt][q4 * 4 + 0]), a1 = round_bf16(acc[n4][mt][q4 * 4 + 1]);
+                    const float a2 = round_bf16(acc[n4][mt][q4 * 4 + 2]), a3 = round_bf16(acc[n4][mt][q4 * 4 + 3]);
+                    u32x2 out;
+                    out[0] = pack_bf16x2(a0 + __uint_as_float(old[0] << 16), a1 + __uint_as_float(old[0] & 0xffff0000u));
+                    out[1] = pack_bf16x2(a2 + __uint_as_float(old[1] << 16), a3 + __uint_as_float(old[1] & 0xffff0000u));
+                    *(u32x2 *)(crow + n) = out;
+                }
             }
         }
     }
