@@ -533,7 +533,10 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
              "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
-    pp.xcd_chunks = chipmunk_get_option("attn_xcd_chunks");
+    // block -> XCD mapping: 1 = every XCD walks its own contiguous (head, group) range, 0 = all XCDs sweep one head
+    // together; option value 2 = chunks for the gathered launches only
+    const int xo = chipmunk_get_option("attn_xcd_chunks");
+    pp.xcd_chunks = xo == 2 ? (GATHER ? 1 : 0) : xo;
     // scratch layout: [tickets: TICKET_BYTES, always left at zero][work order | split partials]
     constexpr size_t TICKET_BYTES = 64 << 10;
     if (GATHER && nblocks >= 2048 && !chipmunk_get_option("attn_no_order")) {
