@@ -28,7 +28,7 @@ constexpr int TILE_BYTES = KVT * HD * 2;  // 8 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;  // csp_128_attn.cu:307
 constexpr int KEY_RING_OFF = 2 * NST * TILE_BYTES;
 constexpr int CS_OFF = KEY_RING_OFF + KRING * 256;
-constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * KVT * 4;
+constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * 4 * KVT * 4;  // column-sum partials [2 tiles][4 waves][KVT]
 
 struct AttnParams {
     const uint16_t *q, *k, *v;
@@ -72,14 +72,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // exp2(s*c - m*c) * (exp2(m*c) * prev_l) does not depend on the max that centres it, so the pass evaluates it as
 // exp2(s*c + log2(prev_l)) -- one fma, one exp2 and one add per score (the pass is VALU-bound: v_exp_f32 is quarter
 // rate, every other op saved is ~8% of its time) -- in fp32, without the reference's two intermediate bf16 roundings.
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KEYOFF = (CSONLY ? 1 : 2) * NST * TILE_BYTES;  // the column-sum pass has no V ring
     unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
     unsigned char *Vl = smem + NST * TILE_BYTES;   // [NST][TILE_BYTES]
     int *key_ring = (int *)(smem + KEYOFF);        // [KRING][64]
-    float *cs_acc = (float *)(smem + KEYOFF + KRING * 256);  // [2][KVT]
+    // [2][4][KVT]: per-wave column-sum partials of the CSONLY pass, summed in wave order (the reference reduces with
+    // shared-memory atomics and is order-dependent in the last bits; this is run-to-run deterministic)
+    float *cs_acc = (float *)(smem + KEYOFF + KRING * 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 
     int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     int sp = 0, nsp = 1, tail_item = 0;
-    if (!COLSUM && !CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
+    if (!CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
         const int k = wid0 - p.split_full;
         tail_item = k / p.nsplit;
         sp = k - tail_item * p.nsplit;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
     const int valid = count < p.Nk ? count : p.Nk;
     const int ntiles = (valid + KVT - 1) / KVT;
-    if (!COLSUM && !CSONLY && nsp > 1) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
+    if (!CSONLY && nsp > 1) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
         const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
         nsp = nsp < cap ? nsp : cap;
         if (sp >= nsp) return;
@@ -128,23 +130,17 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
 
-    float prevl[3] = {0.f, 0.f, 0.f};
     float cs_off[3][4];  // CSONLY: log2(prev_l) of query row qb*16 + lg*4 + r (that pass computes S, not S^T)
-    if constexpr (COLSUM || CSONLY) {
+    if constexpr (CSONLY) {
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
-            const int qrow = row0 + qb * 16 + li;
-            prevl[qb] = qrow < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qrow] : 0.f;
-            if constexpr (CSONLY) {
+        for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qr = row0 + qb * 16 + lg * 4 + r;
-                    const float pl = qr < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
-                    cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -INFINITY;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int qr = row0 + qb * 16 + lg * 4 + r;
+                const float pl = qr < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
+                cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -INFINITY;
             }
-        }
-        if (tid < 2 * KVT) cs_acc[tid] = 0.f;
+        for (int i = tid; i < 2 * 4 * KVT; i += 256) cs_acc[i] = 0.f;
     }
 
     // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
@@ -211,12 +207,12 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if constexpr (COLSUM || CSONLY) {
+        if constexpr (CSONLY) {
             if (t > 0 && tid < KVT) {
                 const int pos = (t - 1) * KVT + tid;
-                float *acc = cs_acc + ((t - 1) & 1) * KVT + tid;
-                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(*acc);
-                *acc = 0.f;
+                float *acc = cs_acc + ((t - 1) & 1) * 4 * KVT + tid;
+                const float tot = (acc[0] + acc[KVT]) + (acc[2 * KVT] + acc[3 * KVT]);  // overwritten next time round
+                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(tot);
             }
         }
         if (t + NST - 1 < tend && (p.probe & 3) != 1) {
@@ -243,7 +239,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
                 return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
             };
-            constexpr int FR = COLSUM ? 2 : 3;  // the column-sum variant is register-bound: 1 read ahead instead of 2
+            constexpr int FR = 3;
             bf16x8 kr[FR];
 #pragma unroll
             for (int i = 0; i < FR - 1; ++i) kr[i] = load_k(i);
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             float x = cacc[0] + cacc[1], y = x;
             lane_swap16(x, y);                  // x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3}
             x += y;                             // lanes 0-15: key li of kt 0, lanes 32-47: key li of kt 1
-            if ((lane & 16) == 0) atomicAdd(cs_acc + (t & 1) * KVT + (lane >> 5) * 16 + li, x);
+            if ((lane & 16) == 0) cs_acc[((t & 1) * 4 + w) * KVT + (lane >> 5) * 16 + li] = x;
             continue;
         }
         if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
@@ -300,7 +296,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             return __builtin_bit_cast(
                 bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
         };
-        constexpr int VR = COLSUM ? 2 : 3;
+        constexpr int VR = 3;
         bf16x8 vr[VR];
 #pragma unroll
         for (int i = 0; i < VR - 1; ++i) vr[i] = load_v(i);
@@ -308,13 +304,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 
         // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
         bf16x8 pb[3];
-        float cacc[2][4];
-        if constexpr (COLSUM) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cacc[kt][r] = 0.f;
-        }
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
             float mx = s[qb][0][0];
@@ -348,25 +337,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 pk[4 + r] = (__bf16)pv[1][r];
             }
             pb[qb] = pk;
-            if constexpr (COLSUM) {
-                // bf16(P) * bf16(exp2(m_run*c) * prev_l), product rounded to bf16 (dense_colsum_attn.cu:268-272).
-                // (this exact form is the only one hipcc allocates without scratch in the fused variant, which sits
-                // on the 256-VGPR cliff; the shipped path is the two-pass one, see chipmunk_dense_colsum_attn)
-                const float rowfac = round_bf16(__builtin_amdgcn_exp2f(msc) * prevl[qb]);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cacc[kt][r] += round_bf16(round_bf16(pv[kt][r]) * rowfac);
-            }
-        }
-        if constexpr (COLSUM) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float tot = row16_sum(cacc[kt][r]);
-                    if (li == 0) atomicAdd(cs_acc + (t & 1) * KVT + kt * 16 + lg * 4 + r, tot);
-                }
         }
 
         // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
@@ -380,17 +350,21 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
 
-    if constexpr (COLSUM || CSONLY) {
+    if constexpr (CSONLY) {
         __syncthreads();
         if (ntiles > 0 && tid < KVT) {
             const int pos = (ntiles - 1) * KVT + tid;
             if (pos < p.Nk)
-                p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(cs_acc[((ntiles - 1) & 1) * KVT + tid]);
+            {
+                const float *acc = cs_acc + ((ntiles - 1) & 1) * 4 * KVT + tid;
+                const float tot = (acc[0] + acc[KVT]) + (acc[2 * KVT] + acc[3 * KVT]);
+                p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(tot);
+            }
         }
     }
 
     if constexpr (CSONLY) return;
-    if (!COLSUM && nsp > 1) {
+    if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
         //      arriver folds the other slices in (the lane layout is the same in every slice, so the merge is the
         //      online-softmax rescale element by element) and alone runs the epilogue.
@@ -420,14 +394,21 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        // fold ALL slices (the own one included, from its published copy) in slice order: the result does not depend on
+        // which workgroup happened to arrive last
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            m[qb] = -INFINITY, lsum[qb] = 0.f;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         for (int s2 = 0; s2 < nsp; ++s2) {
-            if (s2 == sp) continue;
             const f32x4 *oth = (const f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + s2) * (26 * 256) + tid;
             const f32x4 ms = oth[24 * 256], ls = oth[25 * 256];
 #pragma unroll
             for (int qb = 0; qb < 3; ++qb) {
                 const float m_new = fmaxf(m[qb], ms[qb]);
-                if (m_new == -INFINITY) continue;  // both slices empty
+                if (m_new == -INFINITY) continue;  // nothing so far and an empty slice
                 const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
                 const float c = __builtin_amdgcn_exp2f((ms[qb] - m_new) * SCALE_LOG2E);
                 m[qb] = m_new;
@@ -518,9 +499,9 @@ __global__ __launch_bounds__(1024) void attn_order_kernel(const int32_t *counts,
     }
 }
 
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool COLSUM, bool CSONLY = false>
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 int launch_attn(const AttnParams &p, hipStream_t stream) {
-    auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, COLSUM, CSONLY>;
+    auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY>;
     constexpr int LDS = ATTN_LDS_BYTES - (CSONLY ? NST * TILE_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
@@ -555,7 +536,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     int64_t grid = nblocks;
     // Dense launches only by default: a gathered FLUX item is ~45 us of which ~11 us are fixed costs every slice pays
     // again, and the split measured 94 -> 105 us there (option attn_split_gather forces it, for the tests).
-    if (!COLSUM && !CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
+    if (!CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
         (!GATHER || chipmunk_get_option("attn_split_gather"))) {
         const int64_t slots = 2 * (int64_t)device_cu_count();
         const int64_t rem = nblocks <= slots / 2 ? nblocks : nblocks % slots;
@@ -618,7 +599,7 @@ extern "C" int chipmunk_csp_attn(const void *q, const void *k, const void *v, vo
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
     p.o_scale = (float)o_scale;
     p.o_in = p.o;
-    return launch_attn<true, true, false, false>(p, (hipStream_t)stream);
+    return launch_attn<true, true, false>(p, (hipStream_t)stream);
 }
 
 extern "C" int chipmunk_csp_attn_out(const void *q, const void *k, const void *v, const void *o_in, void *o_out,
@@ -640,7 +621,7 @@ extern "C" int chipmunk_csp_attn_out(const void *q, const void *k, const void *v
     p.indices = indices, p.counts = counts;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
     p.o_scale = (float)o_scale;
-    return launch_attn<true, true, false, false>(p, (hipStream_t)stream);
+    return launch_attn<true, true, false>(p, (hipStream_t)stream);
 }
 
 extern "C" int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,
@@ -655,7 +636,7 @@ extern "C" int chipmunk_csp_128_attn(const void *q, const void *k, const void *v
     p.indices = indices, p.counts = counts;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = idx_stride;
     p.o_scale = 1.f;
-    return launch_attn<true, false, false, false>(p, (hipStream_t)stream);
+    return launch_attn<true, false, false>(p, (hipStream_t)stream);
 }
 
 extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
@@ -673,7 +654,7 @@ extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, 
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
-    return launch_attn<false, false, true, false>(p, (hipStream_t)stream);
+    return launch_attn<false, false, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
@@ -693,10 +674,10 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     p.l_out = l, p.p_in = pin, p.cs = (uint16_t *)cs, p.cs_stride = cs_stride;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
-    if (chipmunk_get_option("colsum_fused")) return launch_attn<false, false, true, true>(p, (hipStream_t)stream);
-    // Two passes (measured faster than the fused variant, which sits on the 256-VGPR cliff): (1) dense attention,
-    // (2) a K-only pass that recomputes S^T and reduces the column sums.  They share nothing but their inputs.
+    // Two passes: (1) dense attention, (2) a K-only pass that recomputes the scores and reduces the column sums; they
+    // share nothing but their inputs.  (A single fused pass was built first: it sat on the 256-VGPR cliff and measured
+    // 885 vs 480 us at FLUX size, 36.9 vs 23.5 ms for two HunyuanVideo heads; removed.)
     hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_attn<false, false, true, false>(p, st);
-    return rc != CHIPMUNK_OK ? rc : launch_attn<false, false, false, false, true>(p, st);
+    const int rc = launch_attn<false, false, true>(p, st);
+    return rc != CHIPMUNK_OK ? rc : launch_attn<false, false, false, true>(p, st);
 }

@@ -1,0 +1,65 @@
+"""The module state machines on the GPU: every fused path of this build (GLOBAL_CONFIG keys in util/config.py:
+AMD_EXTRA_KEYS) against the reference's op sequence on the same device, over a schedule that covers dense layers, full
+steps, mask-reuse steps and sparse steps.  Fusions must not change a single bit."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_flux_schedule(fused: bool, steps: int = 13):
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd.util import config as cfg
+    from chipmunk_amd.util import layer_counter as lc
+    from chipmunk_amd.util.layer_counter import LayerCounter
+    from chipmunk_amd.modules import SparseDiffAttn, SparseDiffMlp
+    cfg.reset_to_base()
+    lc.singleton.__init__(0, 0)
+    cfg.load_from_file(os.path.join(ROOT, "configs", "flux_c2.yml"))
+    g = cfg.GLOBAL_CONFIG
+    g["steps"] = 50
+    g["mlp"]["first_n_dense_layers"] = g["attn"]["first_n_dense_layers"] = 1
+    for sec, key in (("attn", "fused_residual"), ("mlp", "fused_scatter"), ("mlp", "fused_topk_delta")):
+        g[sec][key] = fused
+    dev = torch.device("cuda:0")
+    H, N, HID, FFN, n_layers = 3, 1152, 512, 2048, 3
+    gen = torch.Generator(device=dev).manual_seed(77)
+    layers = []
+    for _ in range(n_layers):
+        num, counter = LayerCounter.build_for_layer(is_mlp_sparse=True, is_attn_sparse=True)
+        fc1 = torch.nn.Linear(HID, FFN, device=dev, dtype=torch.bfloat16)
+        fc2 = torch.nn.Linear(FFN, HID, device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            for prm in (fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+                prm.copy_((torch.randn(prm.shape, device=dev, generator=gen) * 0.05).to(torch.bfloat16))
+        layers.append((SparseDiffAttn(num, counter), SparseDiffMlp(num, counter, fc1, torch.nn.GELU(approximate="tanh"), fc2, 6)))
+    q0, k0, v0, dq = [torch.randn(1, H, N, 128, device=dev, generator=gen) for _ in range(4)]
+    x0, dx = [torch.randn(1, N, HID, device=dev, generator=gen) for _ in range(2)]
+    outs = []
+    with torch.no_grad():
+        for step in range(steps):
+            a = 0.05 * step
+            q = (q0 + a * dq).to(torch.bfloat16)
+            x = (x0 + a * dx).to(torch.bfloat16)
+            for attn, mlp in layers:
+                outs.append(attn(q, k0.to(torch.bfloat16), v0.to(torch.bfloat16)).clone())
+                outs.append(mlp(x).clone())
+    cfg.reset_to_base()
+    lc.singleton.__init__(0, 0)
+    return outs
+
+
+def test_fused_paths_do_not_change_a_bit_over_a_flux_schedule():
+    """13 steps x 3 blocks (block 0 dense): attention full at steps 0, 1, 10, MLP full at 0, 10, MLP mask recomputed every
+    other step -- with fused_residual / fused_scatter / fused_topk_delta on vs off."""
+    fused = _run_flux_schedule(True)
+    plain = _run_flux_schedule(False)
+    assert len(fused) == len(plain) == 13 * 3 * 2
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert a.shape == b.shape and torch.isfinite(a.float()).all(), i
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"output {i} (step {i // 6}, block {(i % 6) // 2}, {'mlp' if i % 2 else 'attn'})"
+    # and the sparse steps actually differ from step to step (the schedule is exercised, not a constant)
+    assert not torch.equal(fused[6 * 2 + 3], fused[6 * 3 + 3])
