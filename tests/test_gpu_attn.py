@@ -186,3 +186,46 @@ def test_dense_colsum_attn(dev, n):
     pad = G * 192 - n
     p = torch.nn.functional.pad(p, (0, 0, 0, pad)).view(1, H, G, 192, n).sum(3)
     assert_close_bf16(cs, p, atol=4e-3, rtol=4e-2, what="colsum cs vs fp32 formula")
+
+
+def test_batched_inputs_all_attention_ops(dev):
+    """B = 2 (the reference kernels pin the batch index to 0, csp_128_attn.cu:82; the C ABI takes B): every attention op
+    against the oracle, which loops over the batch."""
+    B, H, n, count = 2, 2, 768, 256
+    q, k, v = _qkv(B, H, n, n, seed=61)
+    G = n // 192
+    inds, counts = random_index_sets(B, H, G, n, count, n, seed=12)
+    counts[1, 0, 1] = 128
+    qd, kd, vd, indd, cntd = [t.to(dev) for t in (q, k, v, inds, counts)]
+    o_ref, l_ref = oracle.dense_attn(q, k, v)
+    o, l = torch.ops.chipmunk.dense_attn(qd, kd, vd)
+    assert_close_bf16(o, o_ref, what="dense B=2")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    assert_close_bf16(torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd), oracle.csp_128_attn(q, k, v, inds, counts),
+                      what="csp_128 B=2")
+    base = randn_bf16(B, H, n, 128, seed=62)
+    ref = base.clone()
+    oracle.csp_attn(q, k, v, ref, inds, counts, -1)
+    got = base.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, got, indd, cntd, -1)
+    assert_close_bf16(got, ref, atol=3e-2, what="csp_attn B=2")
+    assert torch.equal(torch.ops.chipmunk.csp_attn_out(qd, kd, vd, base.to(dev), indd, cntd, -1), got)
+    o2_ref, cs_ref, l2_ref = oracle.dense_colsum_attn(q, k, v, l_ref)
+    o2, cs, l2 = torch.ops.chipmunk.dense_colsum_attn(qd, kd, vd, l)
+    assert_close_bf16(o2, o2_ref, what="colsum o B=2")
+    assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what="colsum cs B=2")
+
+
+def test_packed_positions_past_the_key_count_are_masked(dev):
+    """right_fill (csp_128_attn.cu:314): with more queries than keys, packed positions >= N_k are masked even when
+    counts says otherwise -- the kernel clamps counts to N_k like the oracle does."""
+    H, n, nk = 1, 768, 384
+    q, k, v = _qkv(1, H, n, nk, seed=71)
+    G = n // 192
+    inds = torch.arange(n, dtype=torch.int32).remainder(nk).view(1, 1, 1, n).expand(1, H, G, n).contiguous()
+    counts = torch.full((1, H, G), 640, dtype=torch.int32)  # > nk: only the first nk packed positions count
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what="right_fill")
+    sdpa = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert_close_bf16(o, sdpa, what="right_fill == attention over all nk keys")
