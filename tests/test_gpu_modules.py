@@ -63,3 +63,58 @@ def test_fused_paths_do_not_change_a_bit_over_a_flux_schedule():
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"output {i} (step {i // 6}, block {(i % 6) // 2}, {'mlp' if i % 2 else 'attn'})"
     # and the sparse steps actually differ from step to step (the schedule is exercised, not a constant)
     assert not torch.equal(fused[6 * 2 + 3], fused[6 * 3 + 3])
+
+
+def test_ops_are_hipgraph_capturable():
+    """Every launch goes to the stream it is given and nothing allocates / synchronises / reads back on the host once the
+    per-stream scratch has its size: a sparse-step op sequence (gathered attention with residual, GEMM1 + scatter, GEMM2,
+    fused top-k, packed mask -> indices, dense attention with its key-split tail) is captured into a graph and replayed."""
+    import math
+    import chipmunk_amd  # noqa: F401
+    from helpers import randn_bf16, random_index_sets
+    dev = torch.device("cuda:0")
+    H, n, count = 2, 1152, 384
+    G = math.ceil(n / 192)
+    q, k, v, base = [randn_bf16(1, H, n, 128, seed=s).to(dev) for s in (1, 2, 3, 4)]
+    inds, counts = [t.to(dev) for t in random_index_sets(1, H, G, n, count, n, seed=5)]
+    M, K, F = 256, 256, 1024
+    x, w1 = randn_bf16(M, K, seed=6, scale=0.5).to(dev), randn_bf16(F, K, seed=7, scale=0.1).to(dev)
+    b1, w2t = randn_bf16(F, seed=8, scale=0.1).to(dev), randn_bf16(F, K, seed=9, scale=0.1).to(dev)
+    cache0, out0 = randn_bf16(F, M, seed=10, scale=0.3).to(dev), randn_bf16(M, K, seed=11).to(dev)
+    bm, bmc0 = randn_bf16(1, M // 128, F, seed=12).to(dev), randn_bf16(1, M // 128, F, seed=13).to(dev)
+    mask = (torch.rand(1, H, G, n, generator=torch.Generator().manual_seed(14)) < 0.2).to(dev)
+    packed = torch.ops.chipmunk.bitpack(mask)
+
+    def step(cache, out, bmc):
+        minds = torch.empty(1, M // 128, F, dtype=torch.int32, device=dev)
+        mcnt = torch.empty(1, M // 128, dtype=torch.int32, device=dev)
+        torch.ops.chipmunk.topk_delta_indices(bm, bmc, minds, mcnt, 0.7, 256, 0.0)
+        c = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+        torch.ops.chipmunk.csp_mlp_mm1_scatter(x, w1, c, b1, cache, minds[0], mcnt[0])
+        torch.ops.chipmunk.csp_mlp_mm2(c, w2t, minds[0], mcnt[0], out)
+        i2, c2 = torch.ops.chipmunk.packed_mask_to_indices(packed, list(mask.shape), 128, 192)
+        o = torch.ops.chipmunk.csp_attn_out(q, k, v, base, inds, counts, 1)
+        o2 = torch.ops.chipmunk.csp_128_attn(q, k, v, i2, c2)
+        od, l = torch.ops.chipmunk.dense_attn(q, k, v)
+        return o, o2, od, l
+
+    eager_state = [cache0.clone(), out0.clone(), bmc0.clone()]
+    eager = step(*eager_state)          # also brings the scratch to its final size
+    torch.cuda.synchronize()
+    graph_state = [cache0.clone(), out0.clone(), bmc0.clone()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(cache0.clone(), out0.clone(), bmc0.clone())   # scratch of the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        captured = step(*graph_state)
+    for t, src in zip(graph_state, (cache0, out0, bmc0)):
+        t.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, captured):
+        assert torch.equal(a, b)
+    for a, b in zip(eager_state, graph_state):
+        assert torch.equal(a, b)
