@@ -28,7 +28,7 @@ constexpr int TILE_BYTES = KVT * HD * 2;  // 8 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;  // csp_128_attn.cu:307
 constexpr int KEY_RING_OFF = 2 * NST * TILE_BYTES;
 constexpr int CS_OFF = KEY_RING_OFF + KRING * 256;
-constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * 4 * KVT * 4;  // column-sum partials [2 tiles][4 waves][KVT]
+constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * 2 * 4 * KVT * 4;  // column-sum partials [2 iterations][2 tiles][4 waves][KVT]
 
 struct AttnParams {
     const uint16_t *q, *k, *v;
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
     unsigned char *Vl = smem + NST * TILE_BYTES;   // [NST][TILE_BYTES]
     int *key_ring = (int *)(smem + KEYOFF);        // [KRING][64]
-    // [2][4][KVT]: per-wave column-sum partials of the CSONLY pass, summed in wave order (the reference reduces with
-    // shared-memory atomics and is order-dependent in the last bits; this is run-to-run deterministic)
+    // [2][2][4][KVT]: per-wave column-sum partials of the CSONLY pass (iteration parity, tile parity, wave), summed in
+    // wave order (the reference reduces with shared-memory atomics and is order-dependent in the last bits; this is
+    // run-to-run deterministic)
     float *cs_acc = (float *)(smem + KEYOFF + KRING * 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 const float pl = qr < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
                 cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -INFINITY;
             }
-        for (int i = tid; i < 2 * 4 * KVT; i += 256) cs_acc[i] = 0.f;
+        for (int i = tid; i < 2 * 2 * 4 * KVT; i += 256) cs_acc[i] = 0.f;
     }
 
     // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         wait_vmcnt<0>();
         __syncthreads();
 #pragma unroll
-        for (int T = 0; T < NST - 1; ++T) {
+        for (int T = 0; T < (CSONLY ? 2 : NST - 1); ++T) {
             if (tbeg + T < tend) {
                 issue_data(tbeg + T);
                 issue_keys(tbeg + T + NST - 1);
@@ -196,25 +197,87 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
 
+    if constexpr (CSONLY) {
+        // ---- column-sum pass: TWO 32-key tiles per barrier (the pass has registers to spare and is bound by the
+        //      per-tile synchronisation, not by a pipe: MFMA 48 % busy with one tile per barrier).  Ring use: tiles
+        //      t, t+1 are consumed while t+2, t+3 land in the other two slots.
+        // S = Q . K^T with the MFMA operands swapped relative to the main loop: s[qb][kt][r] = score(q = qb*16 + lg*4 + r,
+        // kv = kt*16 + li), so a lane owns one key and the sum over the wave's 48 queries is mostly in-lane
+        auto cs_tile = [&](int t, int it) {
+            const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
+            f32x4 s[3][2];
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto load_k = [&](int idx) {
+                const int kt = idx >> 2, ks = idx & 3;
+                const int pc = (ks * 4 + lg) ^ li;
+                return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
+            };
+            bf16x8 kr[3];
+            kr[0] = load_k(0), kr[1] = load_k(1);
+#pragma unroll
+            for (int idx = 0; idx < 8; ++idx) {
+                if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kt = idx >> 2, ks = idx & 3;
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(qf[qb][ks], kr[idx % 3], s[qb][kt]);  // S = Q . K^T
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // exp2(s*c + log2 prev_l), summed over this wave's 48 queries: 12 in-lane terms, then the 4 lane rows
+            float cacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                float a = 0.f;
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        a += __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, cs_off[qb][r]));
+                cacc[kt] = t * KVT + kt * 16 + li < valid ? a : 0.f;
+            }
+            lane_swap32(cacc[0], cacc[1]);      // [0] = {kt0 rows 0-1, kt1 rows 0-1}, [1] = {kt0 rows 2-3, kt1 rows 2-3}
+            float x = cacc[0] + cacc[1], y = x;
+            lane_swap16(x, y);                  // x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3}
+            x += y;                             // lanes 0-15: key li of kt 0, lanes 32-47: key li of kt 1
+            if ((lane & 16) == 0) cs_acc[(((it & 1) * 2 + (t & 1)) * 4 + w) * KVT + (lane >> 5) * 16 + li] = x;
+        };
+        auto flush = [&](int t0, int it) {  // column sums of tiles t0, t0+1 (iteration `it`) -> HBM, by threads 0..63
+            if (tid < 2 * KVT) {
+                const int pos = t0 * KVT + tid;
+                const float *acc = cs_acc + (((it & 1) * 2 + (tid >> 5)) * 4) * KVT + (tid & (KVT - 1));
+                const float tot = (acc[0] + acc[KVT]) + (acc[2 * KVT] + acc[3 * KVT]);
+                if (pos < p.Nk && pos < ntiles * KVT) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(tot);
+            }
+        };
+        int it = 0;
+        for (int t = 0; t < ntiles; t += 2, ++it) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t > 0) flush(t - 2, it - 1);
+            if (t + 2 < ntiles) issue_data(t + 2);
+            if (t + 3 < ntiles) issue_data(t + 3);
+            cs_tile(t, it);
+            if (t + 1 < ntiles) cs_tile(t + 1, it);
+        }
+        __syncthreads();
+        if (ntiles > 0) flush((ntiles - 1) & ~1, it - 1);
+        return;
+    }
+
     for (int t = tbeg; t < tend; ++t) {
         const int slot = t % NST;
         // tile t has landed once at most the NST-2 younger groups (4 DMAs each, +1 key DMA on wave 0) are in flight
         if (t + NST - 1 <= tend) {
-            constexpr int L = CSONLY ? 2 : 4;  // DMA instructions per wave per tile
+            constexpr int L = 4;  // DMA instructions per wave per tile
             if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
             else wait_vmcnt<(NST - 2) * L>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if constexpr (CSONLY) {
-            if (t > 0 && tid < KVT) {
-                const int pos = (t - 1) * KVT + tid;
-                float *acc = cs_acc + ((t - 1) & 1) * 4 * KVT + tid;
-                const float tot = (acc[0] + acc[KVT]) + (acc[2 * KVT] + acc[3 * KVT]);  // overwritten next time round
-                if (pos < p.Nk) p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(tot);
-            }
-        }
         if (t + NST - 1 < tend && (p.probe & 3) != 1) {
             issue_data(t + NST - 1);
             issue_keys(t + 2 * (NST - 1));
@@ -224,8 +287,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         const unsigned char *Vb = Vl + slot * TILE_BYTES;
 
         // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
-        //      (CSONLY: S = Q . K^T with the operands swapped, s[qb][kt][r] = score(q = qb*16 + lg*4 + r, kv = kt*16 + li),
-        //       so that the sum over queries is mostly in-lane)
         f32x4 s[3][2];
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
@@ -250,31 +311,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 const int kt = idx >> 2, ks = idx & 3;
 #pragma unroll
                 for (int qb = 0; qb < 3; ++qb)
-                    s[qb][kt] = CSONLY ? mfma16(qf[qb][ks], kr[idx % FR], s[qb][kt]) : mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
+                    s[qb][kt] = mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
-        if constexpr (CSONLY) {
-            // exp2(s*c + log2 prev_l), summed over this wave's 48 queries: 12 in-lane terms, then the 4 lane rows
-            float cacc[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                float a = 0.f;
-#pragma unroll
-                for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        a += __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, cs_off[qb][r]));
-                cacc[kt] = t * KVT + kt * 16 + li < valid ? a : 0.f;
-            }
-            lane_swap32(cacc[0], cacc[1]);      // [0] = {kt0 rows 0-1, kt1 rows 0-1}, [1] = {kt0 rows 2-3, kt1 rows 2-3}
-            float x = cacc[0] + cacc[1], y = x;
-            lane_swap16(x, y);                  // x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3}
-            x += y;                             // lanes 0-15: key li of kt 0, lanes 32-47: key li of kt 1
-            if ((lane & 16) == 0) cs_acc[((t & 1) * 4 + w) * KVT + (lane >> 5) * 16 + li] = x;
-            continue;
-        }
         if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -350,20 +391,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
 
-    if constexpr (CSONLY) {
-        __syncthreads();
-        if (ntiles > 0 && tid < KVT) {
-            const int pos = (ntiles - 1) * KVT + tid;
-            if (pos < p.Nk)
-            {
-                const float *acc = cs_acc + ((ntiles - 1) & 1) * 4 * KVT + tid;
-                const float tot = (acc[0] + acc[KVT]) + (acc[2 * KVT] + acc[3 * KVT]);
-                p.cs[((int64_t)bh * p.G + g) * p.cs_stride + pos] = f32_to_bf16_bits(tot);
-            }
-        }
-    }
-
-    if constexpr (CSONLY) return;
     if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
         //      arriver folds the other slices in (the lane layout is the same in every slice, so the merge is the
