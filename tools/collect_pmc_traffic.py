@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {  # json key -> substring of the kernel name
     "mm1": "mm1_kernel", "mm2": "mm2_kernel", "scatter_add": "scatter_add_kernel",
-    "csp_attn": "attn_kernel<true, true", "dense_attn": "attn_kernel<false, false, true, false, false>",
+    "csp_attn": "attn_kernel<true, true", "dense_attn": "attn_kernel<false, false, true, false>",
 }
 
 
