@@ -1,19 +1,21 @@
-// Column-sparse / dense attention for gfx950 (MI355X), one templated kernel behind four C-ABI entry points.
+// Column-sparse / dense attention for gfx950 (MI355X), one templated kernel behind five C-ABI entry points.
 //
 // Replaces the reference's four Hopper kernels (csrc/attn/{csp_attn,csp_128_attn,dense_attn,dense_colsum_attn}.cu).
 // Nothing of their structure (TMA, WGMMA, producer/consumer warpgroups, 112/128-row KV tiles) is kept; the design is
 // CDNA4-first:
 //   * one workgroup = one (batch, head, 192-query group) = 4 waves x 48 query rows, one wave per SIMD,
-//     two workgroups per CU (LDS 64.5 KiB each) so every SIMD holds two waves;
+//     two workgroups per CU (LDS 68.5 KiB each) so every SIMD holds two waves;
 //   * "swapped" QK^T: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16, so a lane owns ONE query column and its softmax
 //     statistics (running max, partial sum, rescale factor) are lane-local scalars;
 //   * P^T (bf16) is consumed straight from registers as the B operand of O^T += V^T.P^T -- the k-order permutation of
 //     the accumulator layout is absorbed by the order in which V^T fragments are fetched (ds_read_b64_tr_b16);
-//   * K/V rows (256 B each) are gathered HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): the per-lane global
-//     address does the gather, the XOR swizzle of the 16-byte chunk index is applied on the SOURCE address so the
-//     lane-linear LDS image is bank-conflict-free for ds_read_b128 (K) and ds_read_b64_tr_b16 (V);
-//   * 2-deep LDS ring, gather indices prefetched one tile further ahead, one barrier per 64-key tile;
-//   * XCD-aware block remap: each XCD walks a contiguous range of (head, group) so one head's K/V stays in its L2.
+//   * K/V rows (256 B each) are gathered L2 -> LDS by buffer-form LDS-DMA: the per-lane offset does the gather, the XOR
+//     swizzle of the 16-byte chunk index is applied on the SOURCE side so the lane-linear LDS image is
+//     bank-conflict-free for ds_read_b128 (K) and ds_read_b64_tr_b16 (V);
+//   * 32-key tiles in a 4-slot LDS ring (3 tiles in flight), gather indices travelling further ahead through an LDS
+//     key ring, one raw s_barrier + counted vmcnt per tile;
+//   * scheduling across workgroups: longest-first order for ragged key counts, key-split tail with a last-arriver merge
+//     for near-equal items (see launch_attn); no float atomics, every reduction has a fixed order.
 #include "common.h"
 
 namespace {
@@ -70,8 +72,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // CSONLY = second pass of dense_colsum_attn: only K is staged, S^T is recomputed and reduced to the 192-row column sums;
 // no softmax state, no V, no O accumulators (so it runs at twice the occupancy).  The reference's summand
 // exp2(s*c - m*c) * (exp2(m*c) * prev_l) does not depend on the max that centres it, so the pass evaluates it as
-// exp2(s*c + log2(prev_l)) -- one fma, one exp2 and one add per score (the pass is VALU-bound: v_exp_f32 is quarter
-// rate, every other op saved is ~8% of its time) -- in fp32, without the reference's two intermediate bf16 roundings.
+// exp2(s*c + log2(prev_l)) -- one fma, one exp2 and one add per score -- in fp32, without the reference's two
+// intermediate bf16 roundings.  It has its own loop (two key tiles per barrier) right after the prologue.
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -2,13 +2,15 @@
 // Replaces reference csrc/mlp/csp_mlp_mm1.cu, csrc/mlp/csp_mlp_mm2_and_scatter_add.cu (+ the Triton GEMM
 // src/chipmunk/triton/csp_mlp_mm2.py) and csrc/indexed_io/scatter_add.cu.
 //
-// Both GEMMs: workgroup tile 128 rows (one sparsity group, reference bm = 128) x 256 packed columns, K step 64,
-// 4 waves (2x2), each wave a 64x128 accumulator of v_mfma_f32_32x32x16_bf16 tiles (128 fp32 VGPRs/lane), one wave
-// per SIMD, one workgroup per CU, 2-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4).  The gather is the
-// per-lane source address of the DMA: fc1 rows (mm1) are 2*K contiguous bytes, fc2^T rows (mm2) are 2*N2 contiguous
-// bytes, so every gathered piece is a full 128-byte line.  XOR swizzles are applied on the source chunk index so the
-// lane-linear LDS image is conflict-free for ds_read_b128 (k-contiguous operands) and ds_read_b64_tr_b16 (fc2^T,
-// which is n-contiguous in memory and must be fed k-contiguous to the MFMA).
+// Both GEMMs: workgroup tile = 128 rows (one sparsity group, reference bm = 128) x BN packed columns, K step BK, 4 or 8
+// waves, v_mfma_f32_32x32x16_bf16 accumulators, NST-deep LDS ring filled by buffer-form LDS-DMA
+// (buffer_load_dwordx4 ... lds) with counted vmcnt across a raw s_barrier; shapes are template parameters, the shipped
+// ones are GEMM1 <128 cols, K step 64, 2 stages, 2 workgroups/CU, 4 waves of 64x64> and GEMM2 <256, 32, 3, 2, 8 waves
+// of 64x64>.  The gather is the per-lane source offset of the DMA: fc1 rows (mm1) are 2*K contiguous bytes, fc2^T rows
+// (mm2) are 2*N2 contiguous bytes, so every gathered piece is a full 128-byte line.  XOR swizzles are applied on the
+// source chunk index so the lane-linear LDS image is conflict-free for ds_read_b128 (k-contiguous operands) and
+// ds_read_b64_tr_b16 (fc2^T, which is n-contiguous in memory and must be fed k-contiguous to the MFMA).  Epilogues go
+// through the freed ring so that global memory only sees 16-byte accesses over whole row segments.
 #include "common.h"
 
 namespace {
