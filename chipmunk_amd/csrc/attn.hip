@@ -4,7 +4,7 @@
 // Nothing of their structure (TMA, WGMMA, producer/consumer warpgroups, 112/128-row KV tiles) is kept; the design is
 // CDNA4-first:
 //   * one workgroup = one (batch, head, 192-query group) = 4 waves x 48 query rows, one wave per SIMD,
-//     two workgroups per CU (LDS 68.5 KiB each) so every SIMD holds two waves;
+//     two workgroups per CU (LDS 68 KiB each) so every SIMD holds two waves;
 //   * "swapped" QK^T: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16, so a lane owns ONE query column and its softmax
 //     statistics (running max, partial sum, rescale factor) are lane-local scalars;
 //   * P^T (bf16) is consumed straight from registers as the B operand of O^T += V^T.P^T -- the k-order permutation of

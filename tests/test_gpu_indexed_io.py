@@ -205,3 +205,37 @@ def test_topk_mask_ties_and_random(dev):
     assert (extra[~groups.squeeze(-1)] == 0).all()
     assert ((extra[groups.squeeze(-1)] > 30) & (extra[groups.squeeze(-1)] < 130)).all()  # ~1 % of 7192
     assert (out_r | ~out)[groups.expand_as(out)].all()  # the random part only adds
+
+
+def test_c_abi_called_directly_without_the_torch_registry(dev):
+    """The boundary is the C ABI: call two entry points through ctypes (device pointers + sizes + the raw stream handle)
+    and compare with the oracle -- no torch types cross the call."""
+    import ctypes
+    from chipmunk_amd import _native
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(21)
+    mask = torch.rand(3, 700, generator=g) < 0.3
+    rows, n, pad_n = 3, 700, 768
+    md = mask.to(dev)
+    inds = torch.full((rows, pad_n), -7, dtype=torch.int32, device=dev)
+    counts = torch.zeros(rows, dtype=torch.int32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.chipmunk_mask_to_indices(ctypes.c_void_p(md.data_ptr()), ctypes.c_void_p(inds.data_ptr()),
+                                      ctypes.c_void_p(counts.data_ptr()), ctypes.c_int64(rows), ctypes.c_int(n),
+                                      ctypes.c_int(pad_n), ctypes.c_int(128), stream)
+    assert rc == 0, _native.last_error()
+    ref_i, ref_c = oracle.mask_to_indices(mask.view(1, 1, rows, n), 128, 192)   # pads 700 -> 768 columns, like pad_n
+    torch.cuda.synchronize()
+    assert torch.equal(counts.cpu(), ref_c.view(-1))
+    for r in range(rows):
+        c = int(ref_c.view(-1)[r])
+        assert torch.equal(inds[r, :c].cpu(), ref_i.view(rows, -1)[r, :c])
+    packed = torch.zeros((rows * n + 7) // 8, dtype=torch.uint8, device=dev)
+    rc = lib.chipmunk_bitpack(ctypes.c_void_p(md.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.c_int64(rows * n), stream)
+    assert rc == 0, _native.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(packed.cpu(), oracle.bitpack(mask)[0])
+    # a bad argument comes back as an error code with a message, not an exception or an exit
+    rc = lib.chipmunk_mask_to_indices(None, ctypes.c_void_p(inds.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                      ctypes.c_int64(rows), ctypes.c_int(n), ctypes.c_int(pad_n), ctypes.c_int(128), stream)
+    assert rc != 0 and _native.last_error()
