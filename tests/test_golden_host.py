@@ -158,3 +158,18 @@ def test_f8linear_scale_arithmetic_matches_reference(tag, in_dt):
         assert torch.equal(q.input_scale, want["input_scale"]), f"call {i}"
         assert torch.equal(q.input_scale_reciprocal, want["input_scale_reciprocal"]), f"call {i}"
         assert bool(q.input_scale_initialized) == want["initialized"] and int(q.trial_index) == want["trial_index"], f"call {i}"
+
+
+@pytest.mark.parametrize("t,h,w,vox", [(4, 6, 9, (4, 4, 4)), (33, 45, 10, (4, 4, 4)), (33, 45, 80, (4, 6, 8))])
+def test_voxel_chunk_properties_of_the_reference_tests(t, h, w, vox):
+    """The assertions of the reference's own tests (src/chipmunk/tests/test_voxel.py:12-139): the first two voxels of
+    the reordered sequence are the first two (vt, vh, vw) bricks of the grid, and the reverse op is an exact inverse --
+    including grids that are not multiples of the voxel shape (the HunyuanVideo 33 x 45 latent)."""
+    from chipmunk_amd.ops import voxel
+    x = torch.arange(t * h * w).view(1, 1, t, h, w, 1).expand(1, 3, -1, -1, -1, -1).contiguous()
+    vt, vh, vw = vox
+    n = vt * vh * vw
+    vx = voxel.voxel_chunk_no_padding(x, voxel_shape=vox)
+    assert torch.equal(vx[:, :, :n, 0].flatten(), x[:, :, :vt, :vh, :vw, :].flatten())
+    assert torch.equal(vx[:, :, n:2 * n, 0].flatten(), x[:, :, :vt, :vh, vw:2 * vw, :].flatten())
+    assert torch.equal(voxel.reverse_voxel_chunk_no_padding(vx, (1, 3, t, h, w, 1), voxel_shape=vox), x)
