@@ -12,6 +12,7 @@
 // ds_read_b64_tr_b16 (fc2^T, which is n-contiguous in memory and must be fed k-contiguous to the MFMA).  Epilogues go
 // through the freed ring so that global memory only sees 16-byte accesses over whole row segments.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -113,14 +114,19 @@ struct Mm1Params {
     uint16_t *c;
     const int32_t *indices, *counts;
     int M, K, F, NT, NR, probe, slots_per_xcd;
-    int update_cache;  // 1: also apply the scatter-add of this tile's deltas to the cache block it already holds in LDS
+    int update_cache;  // 1: also apply the scatter-add of this tile's deltas to the cache block it already holds in LDS;
+                       // 2 (fp8): store the new activation into the cache like the reference's Triton kernel
+    const float *scale_a, *scale_b;  // fp8 only: reciprocal quantisation scales (one float each)
 };
 
 // One TM x TN output tile (TM rows of group g starting at m_off, packed columns n0 .. n0+TN-1): 4 waves as 2 x 2, each a
 // (TM/2) x (TN/2) accumulator of 32x32x16 MFMA tiles; NST-deep LDS ring of [A tile | B tile] stages.
-template <int TM, int TN, int BK, int NST>
+// FP8: operands are OCP e4m3 bytes (BASELINE config C5; reference src/chipmunk/triton/csp_mlp_mm1.py:37-164); BK then
+// still counts 2-byte units, i.e. a k step is BK*2 = 128 bytes of every row either way.
+template <int TM, int TN, int BK, int NST, bool FP8 = false>
 __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem, int g, int m_off, int n0, int cnt) {
     using KT = KTile<BK>;
+    constexpr uint32_t ESZ = FP8 ? 1u : 2u;  // operand element size in bytes
     constexpr int A_TILE = TM * BK * 2, B_TILE = TN * BK * 2, STAGE = A_TILE + B_TILE;
     constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;  // DMA instructions per wave per tile
     constexpr int MT = TM / 64, NT4 = TN / 64;                      // 32-wide m / n tiles per wave
@@ -135,14 +141,14 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
         const int row = KT::lane_row(w * A_INST + i, lane);
-        aoff[i] = ((uint32_t)(g * BM + m_off + row) * p.K + KT::src_chunk_elems(row, lane)) * 2u;
+        aoff[i] = (uint32_t)(g * BM + m_off + row) * p.K * ESZ + KT::src_chunk_elems(row, lane) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
         const int row = KT::lane_row(w * B_INST + i, lane);
         const int j = n0 + row;
         const int key = idxg[j < cnt ? j : n0];  // rows past the count re-read a live row and are never stored
-        boff[i] = ((uint32_t)key * p.K + KT::src_chunk_elems(row, lane)) * 2u;
+        boff[i] = (uint32_t)key * p.K * ESZ + KT::src_chunk_elems(row, lane) * 2u;
     }
     auto issue = [&](int kb, int buf) {
         unsigned char *st = smem + buf * STAGE;
@@ -157,6 +163,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     // 16-byte row-major stores.  (Direct form: 8-byte gathered loads and 2-byte stores, 64 of each per lane --
     // measured 34 us of a 148 us launch.)
     constexpr bool STAGED = TM * TN * 2 <= STAGE;
+    static_assert(!FP8 || STAGED, "the fp8 form is only built for tile shapes with the staged epilogue");
     constexpr int LPR = TM * 2 / 16;                                  // 16-byte chunks per cache row
     constexpr int C_INST = STAGED ? TM * TN * 2 / 4096 : 1;           // DMA instructions per wave
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.cache);
@@ -185,7 +192,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][n4][r] = 0.f;
 
-    const int nkb = p.K / BK;
+    const int nkb = (int)((uint32_t)p.K * ESZ / (BK * 2));
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < nkb) issue(s, s);
@@ -206,14 +213,19 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         const unsigned char *Bt = At + A_TILE;
         // operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are in flight while the
         // MFMAs of slice kk issue (left to itself hipcc emits read -> lgkmcnt(0) -> 4 MFMA -> read ...)
-        constexpr int KK = BK / 16;
-        bf16x8 af[2][MT], bfr[2][NT4];
+        // one MFMA k slice = 16 elements: 32 bytes of a row in bf16 (16 per lane half), 16 bytes in fp8 (8 per half)
+        constexpr int KK = FP8 ? BK / 8 : BK / 16;
+        using Frag = typename std::conditional<FP8, long, bf16x8>::type;
+        Frag af[2][MT], bfr[2][NT4];
+        auto frag = [&](const unsigned char *tile, int row, int kk) -> Frag {
+            if constexpr (FP8) return *(const long *)(tile + row * (BK * 2) + ((kk ^ KT::swz(row)) << 4) + ((lane >> 5) << 3));
+            else return KT::frag(tile, row, kk, lane);
+        };
         auto load_frags = [&](int kk, int set) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[set][mt] = KT::frag(At, wm * (TM / 2) + mt * 32 + (lane & 31), kk, lane);
+            for (int mt = 0; mt < MT; ++mt) af[set][mt] = frag(At, wm * (TM / 2) + mt * 32 + (lane & 31), kk);
 #pragma unroll
-            for (int n4 = 0; n4 < NT4; ++n4)
-                bfr[set][n4] = KT::frag(Bt, wn * (TN / 2) + n4 * 32 + (lane & 31), kk, lane);
+            for (int n4 = 0; n4 < NT4; ++n4) bfr[set][n4] = frag(Bt, wn * (TN / 2) + n4 * 32 + (lane & 31), kk);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -223,8 +235,12 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int n4 = 0; n4 < NT4; ++n4)
-                    acc[mt][n4] = mfma32(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4]);
+                for (int n4 = 0; n4 < NT4; ++n4) {
+                    if constexpr (FP8)
+                        acc[mt][n4] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4], 0, 0, 0);
+                    else
+                        acc[mt][n4] = mfma32(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4]);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         buf = buf + 1 == NST ? 0 : buf + 1;
@@ -265,8 +281,19 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                     const u32x2 cv = *(const u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2);
                     const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
                     const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
-                    const float x[4] = {gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0, gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1,
-                                        gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2, gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3};
+                    const float cc[4] = {c0, c1, c2, c3};
+                    float x[4], act[4];  // packed delta before its bf16 rounding; fp8: the new activation (bf16)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (FP8) {
+                            // acc*scale_a*scale_b + bias -> gelu -> bf16, then a bf16 subtract (csp_mlp_mm1.py:121-133)
+                            act[e] = round_bf16(gelu_tanh(acc[mt][n4][q4 * 4 + e] * p.scale_a[0] * p.scale_b[0] + bia));
+                            x[e] = act[e] - cc[e];
+                        } else {
+                            act[e] = 0.f;
+                            x[e] = gelu_tanh(acc[mt][n4][q4 * 4 + e] + bia) - cc[e];
+                        }
+                    }
                     float xr[4];  // the packed deltas as stored (bf16)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -275,10 +302,13 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                         xr[e] = bf16_bits_to_f32(xb);
                         *(uint16_t *)(Ot + r * (TN * 2) + (((jl >> 3) ^ (r & (LPO - 1))) << 4) + (jl & 7) * 2) = xb;
                     }
-                    if (p.update_cache) {  // cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
+                    if (p.update_cache) {
+                        // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98);
+                        // 2: cache = new activation, what the reference's fp8 Triton kernel does (csp_mlp_mm1.py:140)
+                        const bool literal = FP8 && p.update_cache == 2;
                         u32x2 nc;
-                        nc[0] = pack_bf16x2(c0 + xr[0], c1 + xr[1]);
-                        nc[1] = pack_bf16x2(c2 + xr[2], c3 + xr[3]);
+                        nc[0] = literal ? pack_bf16x2(act[0], act[1]) : pack_bf16x2(c0 + xr[0], c1 + xr[1]);
+                        nc[1] = literal ? pack_bf16x2(act[2], act[3]) : pack_bf16x2(c2 + xr[2], c3 + xr[3]);
                         *(u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2) = nc;
                     }
                 }
@@ -341,7 +371,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     }
 }
 
-template <int BN, int BK, int NST, int WPS>
+template <int BN, int BK, int NST, int WPS, bool FP8 = false>
 __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NSUB = 2 * (BN / 64);  // 64 x 64 sub-tiles per tile
@@ -352,152 +382,12 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
     if (tm.sub < 0) {
         const int n0 = tm.nt * BN;
         if (n0 >= cnt) return;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
-        mm1_tile<BM, BN, BK, NST>(p, smem, g, 0, n0, cnt);
+        mm1_tile<BM, BN, BK, NST, FP8>(p, smem, g, 0, n0, cnt);
     } else {
         constexpr int SUB_NST = (NST * (BM + BN)) / 128;  // same LDS bytes, stages of 64 + 64 rows
         const int n0 = tm.nt * BN + (tm.sub >> 1) * 64;
         if (n0 >= cnt || p.probe == 3) return;  // probe 3: time the launch without its tail
-        mm1_tile<64, 64, BK, (SUB_NST > 4 ? 4 : SUB_NST)>(p, smem, g, (tm.sub & 1) * 64, n0, cnt);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ mm1, fp8 e4m3
-// BASELINE config C5 (Wan2.1 shapes): the reference's fp8 GEMM1 is a Triton kernel (src/chipmunk/triton/csp_mlp_mm1.py:
-// 37-164): acc = (A_fp8 . B_fp8[idx]) * scale_a * scale_b; x = bf16(gelu(acc + bias)); packed = bf16(x - cache); and it
-// also stores x into the cache (:140), after which the scatter-add of ops/mlp.py:92 adds the delta a second time -- a
-// reference inconsistency.  `update_cache` selects that literal behaviour (1) or the bf16 path's (0: the
-// cache is left to the scatter-add).  Same tile machinery as the bf16 kernel: 128 bytes of K per row and step (BK = 128
-// fp8 elements), v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3fn on gfx950), 8-byte operand fragments.
-struct Mm1Fp8Params {
-    const unsigned char *a, *b;  // fp8 e4m3fn [M,K], [F,K]
-    const uint16_t *bias;
-    uint16_t *cache, *c;
-    const int32_t *indices, *counts;
-    const float *scale_a, *scale_b;
-    int M, K, F, NT, NR, update_cache;
-};
-
-template <int BN, int NST, int WPS>
-__global__ __launch_bounds__(256, WPS) void mm1_fp8_kernel(const Mm1Fp8Params p) {
-    using KT = KTile<64>;  // geometry in BYTES: 128-byte rows, 8 chunks of 16 B
-    constexpr int BKB = 128;
-    constexpr int A_TILE = BM * BKB, B_TILE = BN * BKB, STAGE = A_TILE + B_TILE;
-    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;
-    constexpr int NT4 = BN / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-
-    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR);
-    if (!tm.live) return;
-    const int g = tm.g, nt = tm.nt;
-    const int cnt = p.counts[g];
-    const int n0 = nt * BN;
-    if (n0 >= cnt) return;
-    const int32_t *idxg = p.indices + (int64_t)g * p.F;
-
-    int aoff[A_INST], boff[B_INST];  // byte offsets
-#pragma unroll
-    for (int i = 0; i < A_INST; ++i) {
-        const int row = KT::lane_row(w * A_INST + i, lane);
-        aoff[i] = (g * BM + row) * p.K + (KT::src_chunk_elems(row, lane) << 1);
-    }
-#pragma unroll
-    for (int i = 0; i < B_INST; ++i) {
-        const int row = KT::lane_row(w * B_INST + i, lane);
-        const int j = n0 + row;
-        const int key = idxg[j < cnt ? j : n0];
-        boff[i] = key * p.K + (KT::src_chunk_elems(row, lane) << 1);
-    }
-    auto issue = [&](int kb, int buf) {
-        unsigned char *st = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < A_INST; ++i) glds16(p.a + aoff[i] + kb * BKB, st + (w * A_INST + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_INST; ++i) glds16(p.b + boff[i] + kb * BKB, st + A_TILE + (w * B_INST + i) * 1024);
-    };
-    // 8 fp8 values (k = 8*(lane>>5) .. +7 of the 16-wide slice kk) of row `row`
-    auto frag = [&](const unsigned char *tile, int row, int kk) {
-        return *(const long *)(tile + row * 128 + ((kk ^ KT::swz(row)) << 4) + ((lane >> 5) << 3));
-    };
-
-    f32x16 acc[2][NT4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int n4 = 0; n4 < NT4; ++n4)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][n4][r] = 0.f;
-
-    const int nkb = p.K / BKB;
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nkb) issue(s, s);
-    int buf = 0, nbuf = NST - 1;
-    for (int kb = 0; kb < nkb; ++kb) {
-        if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kb + NST - 1 < nkb) issue(kb + NST - 1, nbuf);
-        const unsigned char *At = smem + buf * STAGE;
-        const unsigned char *Bt = At + A_TILE;
-        long af[2][2], bfr[2][NT4];
-        auto load_frags = [&](int kk, int set) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[set][mt] = frag(At, wm * 64 + mt * 32 + (lane & 31), kk);
-#pragma unroll
-            for (int n4 = 0; n4 < NT4; ++n4) bfr[set][n4] = frag(Bt, wn * (BN / 2) + n4 * 32 + (lane & 31), kk);
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (kk + 1 < 8) load_frags(kk + 1, (kk + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int n4 = 0; n4 < NT4; ++n4)
-                    acc[mt][n4] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        buf = buf + 1 == NST ? 0 : buf + 1;
-        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
-    }
-
-    const float scale = p.scale_a[0] * p.scale_b[0];
-#pragma unroll
-    for (int n4 = 0; n4 < NT4; ++n4) {
-        const int j = n0 + wn * (BN / 2) + n4 * 32 + (lane & 31);
-        const bool live = j < cnt;
-        const int col = live ? idxg[j] : 0;
-        const float bia = bf16_bits_to_f32(p.bias[col]);
-        uint16_t *crow = p.cache + (int64_t)col * p.M;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int m = g * BM + wm * 64 + mt * 32 + q4 * 8 + (lane >> 5) * 4;
-                const u32x2 cv = *(const u32x2 *)(crow + m);
-                float x[4], cc[4] = {__uint_as_float(cv[0] << 16), __uint_as_float(cv[0] & 0xffff0000u),
-                                     __uint_as_float(cv[1] << 16), __uint_as_float(cv[1] & 0xffff0000u)};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)  // acc*scale_a*scale_b + bias -> gelu -> bf16 (csp_mlp_mm1.py:121-130)
-                    x[r] = round_bf16(gelu_tanh(acc[mt][n4][q4 * 4 + r] * p.scale_a[0] * p.scale_b[0] + bia));
-                (void)scale;
-                if (live) {
-                    uint16_t *cp = p.c + (int64_t)m * p.F + j;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cp[(int64_t)r * p.F] = f32_to_bf16_bits(x[r] - cc[r]);  // bf16 subtract (:133)
-                    if (p.update_cache) {
-                        u32x2 nv;
-                        nv[0] = pack_bf16x2(x[0], x[1]);
-                        nv[1] = pack_bf16x2(x[2], x[3]);
-                        *(u32x2 *)(crow + m) = nv;  // reference stores the new activation (:140)
-                    }
-                }
-            }
-        }
+        mm1_tile<64, 64, BK, (SUB_NST > 4 ? 4 : SUB_NST), FP8>(p, smem, g, (tm.sub & 1) * 64, n0, cnt);
     }
 }
 
@@ -828,11 +718,11 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
     }
 }
 
-template <int BN, int BK, int NST, int WPS>
+template <int BN, int BK, int NST, int WPS, bool FP8 = false>
 int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated = nullptr) {
     constexpr int LDS = NST * (BM * BK * 2 + BN * BK * 2);
     constexpr bool STAGED = BM * BN * 2 <= (BM + BN) * BK * 2;  // mm1_tile's staged epilogue (the one that can scatter)
-    auto kern = mm1_kernel<BN, BK, NST, WPS>;
+    auto kern = mm1_kernel<BN, BK, NST, WPS, FP8>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -865,7 +755,7 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
     CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31) && (int64_t)F * M < (1ll << 31),
              "csp_mlp_mm1: operand too large for 32-bit offsets");
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache,
-                   (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache};
+                   (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache, nullptr, nullptr};
     switch (chipmunk_get_option("mm1_variant")) {
         case 1: return launch_mm1_variant<256, 64, 2, 1>(p, stream, cache_updated);
         case 3: return launch_mm1_variant<128, 64, 3, 1>(p, stream, cache_updated);
@@ -926,19 +816,10 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
     CM_CHECK(a && b && c && bias && pa_cache && scale_a && scale_b, "csp_mlp_mm1_fp8: null tensor pointer");
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
     CM_CHECK(K > 0 && K % 128 == 0, "csp_mlp_mm1_fp8: K must be a positive multiple of 128 (got %d)", K);
-    CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31), "csp_mlp_mm1_fp8: operand too large for 32-bit offsets");
-    constexpr int BN = 128, NST = 2;
-    constexpr int LDS = NST * (BM * 128 + BN * 128);
-    auto kern = mm1_fp8_kernel<BN, NST, 2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    Mm1Fp8Params p = {(const unsigned char *)a, (const unsigned char *)b, (const uint16_t *)bias, (uint16_t *)pa_cache,
-                      (uint16_t *)c, indices, counts, scale_a, scale_b, M, K, F, (F + BN - 1) / BN, 4, update_cache};
-    if (p.NR > p.NT) p.NR = p.NT;
-    hipLaunchKernelGGL(kern, dim3((((M / BM) * p.NT + 7) / 8) * 8), dim3(256), LDS, (hipStream_t)stream, p);
-    CM_LAUNCH_CHECK();
-    return CHIPMUNK_OK;
+    CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31) && (int64_t)F * M < (1ll << 31),
+             "csp_mlp_mm1_fp8: operand too large for 32-bit offsets");
+    // same tile machinery as the bf16 kernel (buffer-form DMA, tail split, staged epilogue); a k step is 128 fp8 values
+    Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
+                   indices, counts, M, K, F, 0, 0, 0, 0, update_cache ? 2 : 0, scale_a, scale_b};
+    return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }

@@ -133,6 +133,29 @@ def bench_mlp(which, variants, M=4352, K=3072, F=12288, keep=4096):
     _native.set_option("mm2_variant", 0)
 
 
+def bench_fp8_wan():
+    """BASELINE config C5 (Wan2.1-1.3B, 832x480x81 -> 32 760 tokens padded to 32 768): fp8 e4m3 GEMM1, M = 32768, K = 1536,
+    F = 8960, keep 0.3 (2688 columns); bf16 GEMM1 at the same shape beside it."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    M, K, F, keep = 32768, 1536, 8960, 2688
+    a = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(F, K, device=dev, generator=g) * 0.02
+    a8, w8 = (a * 16).clamp(-448, 448).to(torch.float8_e4m3fn), (w * 512).clamp(-448, 448).to(torch.float8_e4m3fn)
+    sa, sb = torch.tensor([1 / 16.0], device=dev), torch.tensor([1 / 512.0], device=dev)
+    bias = torch.zeros(F, device=dev, dtype=torch.bfloat16)
+    cache = torch.randn(F, M, device=dev, dtype=torch.bfloat16, generator=g)
+    packed = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+    G = M // 128
+    inds = rand_rows(G, F, keep, g)
+    counts = torch.full((G,), keep, dtype=torch.int32, device=dev)
+    flops = 2.0 * M * K * keep
+    ms = timeit(lambda: torch.ops.chipmunk.csp_mlp_mm1_fp8(a8, w8, packed, bias, cache, inds, counts, sa, sb, False), reps=5)
+    print(f"mm1_fp8 (Wan C5): {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s   (M={M} K={K} F={F} keep={keep})")
+    ab, wb = a.to(torch.bfloat16), w.to(torch.bfloat16)
+    ms = timeit(lambda: torch.ops.chipmunk.csp_mlp_mm1(ab, wb, packed, bias, cache, inds, counts), reps=5)
+    print(f"mm1 bf16 same shape: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s")
+
+
 def sorted_random_indices(H, G, n_keys, count, width, g):
     inds = torch.zeros(1, H, G, width, dtype=torch.int32, device=dev)
     for h in range(H):
@@ -234,6 +257,8 @@ def main():
     for w in args.what:
         if w in ("mm1", "mm1s", "mm2", "scatter"):
             bench_mlp(w, variants)
+        elif w == "fp8_wan":
+            bench_fp8_wan()
         elif w in ("topk", "topkd", "m2i", "copy"):
             bench_io(w)
         else:
