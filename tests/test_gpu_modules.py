@@ -58,6 +58,12 @@ def test_fused_paths_do_not_change_a_bit_over_a_flux_schedule():
     fused = _run_flux_schedule(True)
     plain = _run_flux_schedule(False)
     assert len(fused) == len(plain) == 13 * 3 * 2
+    if any(not torch.equal(a, b) for a, b in zip(fused, plain)):
+        # the dense layers go through torch's GEMM backend: if THAT is not run-to-run deterministic on this box, a bit
+        # comparison across runs says nothing about the fusions
+        again = _run_flux_schedule(False)
+        if any(not torch.equal(a, b) for a, b in zip(plain, again)):
+            pytest.skip("the reference op sequence itself is not run-to-run deterministic here (torch GEMM backend)")
     for i, (a, b) in enumerate(zip(fused, plain)):
         assert a.shape == b.shape and torch.isfinite(a.float()).all(), i
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"output {i} (step {i // 6}, block {(i % 6) // 2}, {'mlp' if i % 2 else 'attn'})"
