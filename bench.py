@@ -1,20 +1,25 @@
 #!/usr/bin/env python
 """bench.py -- DiT denoise steps/sec at fixed sparsity on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (column-sparse attention + column-sparse MLP of every transformer block) over one
-batch of synthetic FLUX.1-dev 1280x768 shapes (BASELINE.json configs[1]):
-  57 blocks (19 double: MLP rows 3840, 38 single: MLP rows 4352), 24 heads x 128, 4352 tokens, hidden 3072, ffn 12288,
-  first 2 blocks dense, attention keeps 672 of 4352 keys (84.6 % sparse), MLP keeps ~30 % (+5 % random) of the columns,
-  full steps per the reference's schedule (attention: steps 0, 1 and every 10th; MLP: every 10th).
-The step loop drives chipmunk_amd.modules.SparseDiffAttn / SparseDiffMlp (the reference's module state machines) so the
-timed region contains everything the reference runs per step: mask/index bookkeeping, top-k, copies, and the kernels.
-Inputs (q, k, v and ten drifting MLP inputs per block) are resident in HBM before the timed region; weights are random-init
-(no network for checkpoints).
+Workloads (synthetic shapes, random-init weights, inputs resident in HBM before the timed region):
+
+* ``hunyuan_c3`` (default at ``--gpus 1``; BASELINE.json configs[2], the configuration the target is quoted on):
+  HunyuanVideo 720x1280x129 -> 33x45x80 latent patches = 118 800 image + 256 text tokens, 24 heads x 128, 60 blocks
+  (first 2 dense).  A "step" = every block's attention through ``chipmunk_amd.modules.SparseDiffAttn`` with the
+  reference's shipped config (``configs/hunyuan_c3.yml`` = examples/hunyuan/chipmunk-config.yml: full steps {0,1,10,40},
+  5 % top keys + 1 % random + text columns ~ 93 % column sparsity, bit-packed masks, caches through the offload
+  manager) plus the block's dense MLP ``fc2(gelu_tanh(fc1(x)))`` (3072 -> 12288 -> 3072; HunyuanVideo runs its MLP
+  dense in the reference, ``mlp.is_enabled: false``).  The step loop is the reference's
+  (examples/hunyuan/hyvideo/modules/models.py:732-835): step-cache check, per block storage wait/prefetch, block.
+  Timed steps are inference steps ``warmup .. warmup+steps-1`` of the 50-step schedule (default 5..24: one mask-
+  recompute step and 19 sparse steps).  Also reported: an 82 % sparsity leg (BASELINE target wording: "80 %"),
+  the dense comparator (SDPA + nn.Linear on the same loop), and a projection over the whole 50-step schedule.
+* ``hunyuan_sp`` (default at ``--gpus N > 1``; configs[3]): the same model sharded over N ranks -- attention
+  head-parallel (24/N heads per rank, RCCL all-to-all over xGMI, pipelined over head chunks so the exchange hides
+  behind attention), MLP sequence-parallel (118 800/N rows per rank).  Strong scaling: total work is fixed.
+* ``flux_c2`` (configs[1]): FLUX.1-dev 1280x768, 57 blocks through SparseDiffAttn + SparseDiffMlp.
 
 Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
-For N > 1 every rank runs an independent replica of the same workload (FLUX is single-GPU in the reference; the path
-has no exchange step, so scaling is "weak" with no data-path collective).  `--workload hunyuan_sp` (head-parallel
-HunyuanVideo attention with RCCL all-to-all, reference examples/hunyuan/hyvideo/modules/head_parallel.py) is selectable.
 """
 from __future__ import annotations
 
@@ -37,13 +42,20 @@ MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="flux_c2", choices=["flux_c2", "hunyuan_sp"])
-    ap.add_argument("--layers", type=int, default=57, help="transformer blocks (57 = FLUX.1-dev)")
-    ap.add_argument("--dense-steps", type=int, default=3, help="steps of the dense rocBLAS/SDPA comparator (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 hunyuan, 50 flux)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5 hunyuan, 50 flux)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "hunyuan_c3", "hunyuan_sp", "flux_c2"])
+    ap.add_argument("--layers", type=int, default=0, help="transformer blocks (default 60 HunyuanVideo / 57 FLUX.1-dev)")
+    ap.add_argument("--dense-steps", type=int, default=-1, help="steps of the dense rocBLAS/SDPA comparator (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seq", type=int, default=0, help="hunyuan_sp only: image tokens (default 118800)")
+    ap.add_argument("--step-caching", action="store_true", help="hunyuan: honour step_caching.skip_step_schedule in the loop")
+    ap.add_argument("--top-keys", type=float, default=None, help="hunyuan: attn.top_keys override (0.17 ~ 82 %% sparsity)")
+    ap.add_argument("--no-82", action="store_true", help="hunyuan: skip the 82 %% sparsity leg")
+    ap.add_argument("--offload", action="store_true", help="hunyuan: caches through pinned host memory (keep_resident_if_fits off)")
+    ap.add_argument("--sp-chunk-heads", type=int, default=1, help="hunyuan_sp: local heads per pipeline chunk")
+    ap.add_argument("--sp-no-overlap", action="store_true", help="hunyuan_sp: exchange on the compute stream (reference order)")
+    ap.add_argument("--sp-no-exchange", action="store_true", help="hunyuan_sp: compute only (probe for the exposed-comm fraction)")
+    ap.add_argument("--grid", default="33,45,80", help="hunyuan: latent patch grid T,H,W (default 720x1280x129)")
     return ap.parse_args()
 
 
@@ -55,6 +67,7 @@ class KernelTimer:
         self.records = {}
         self.last_call = {}
         self.enabled = False
+        self.keep_last_call = True   # probe() re-launches the last call; off for workloads whose arguments are GBs
 
     def wrap(self, name, fn, work_fn):
         def wrapped(*args, **kwargs):
@@ -65,7 +78,8 @@ class KernelTimer:
             out = fn(*args, **kwargs)
             end.record()
             self.records.setdefault(name, []).append((start, end, work_fn(*args, **kwargs)))
-            self.last_call[name] = (fn, args, kwargs, work_fn)
+            if self.keep_last_call:
+                self.last_call[name] = (fn, args, kwargs, work_fn)
             return out
         return wrapped
 
@@ -207,47 +221,298 @@ def build_flux(dev, n_layers, timer):
 
 
 def pmc_traffic(op_name):
-    """HBM bytes per launch of the op's kernels from the committed PMC run (profiles/r01_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kbench.py at the C2 single-block shape, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md; regenerate with tools/collect_pmc_traffic.py).  bench.py cannot collect counters itself; None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        t = json.load(f)
+    """HBM bytes per launch of the op's kernels from the committed PMC runs (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; regenerate with tools/collect_pmc_traffic.py).
+    bench.py cannot collect counters itself; None if no file has the op."""
     parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
-             "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"]}
+             "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
+             "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"]}
     keys = parts.get(op_name, [])
-    if not keys or any(k not in t for k in keys):
-        return None
-    return sum(t[k]["hbm_bytes_per_launch"] for k in keys)
+    for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            t = json.load(f)
+        if keys and all(k in t for k in keys):
+            return sum(t[k]["hbm_bytes_per_launch"] for k in keys)
+    return None
 
 
-# ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(n_layers):
-    """Reference dense CPU path restated by the oracle (kind 'port'), on a bounded sample of the same workload:
-    2 of 24 heads of one layer's dense attention at N=4352 + 128 of the 4352 MLP rows; extrapolated to a full step."""
-    import oracle
+# ------------------------------------------------------------------------------------------------ HunyuanVideo workload
+def _csp128_work(q, k, v, indices, counts):
+    B, H, N, D = q.shape
+    Nk = k.shape[2]
+    csum = counts.sum()      # the closure keeps this scalar only (the index tensor of one call is 7 GB at C3)
+    def work():
+        c = float(csum.item())
+        return 98304.0 * c, 2 * B * H * N * D * 2 + 2 * B * H * Nk * D * 2 + 4 * c   # Q + O + K + V once + indices
+    return work
+
+
+def _dense_work(q, k, v, *a):
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    def work():
+        return 4.0 * B * H * Nq * Nk * D, 2 * B * H * Nq * D * 2 + 2 * B * H * Nk * D * 2
+    return work
+
+
+def _colsum_work(q, k, v, p):
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    def work():  # dense pass + the K-only score pass
+        return 6.0 * B * H * Nq * Nk * D, 3 * B * H * Nq * D * 2 + 3 * B * H * Nk * D * 2 + B * H * ((Nq + 191) // 192) * Nk * 2
+    return work
+
+
+class Hunyuan:
+    """HunyuanVideo block loop on `world` ranks (world 1: everything local)."""
+
+    def __init__(self, dev, rank, world, args, timer):
+        import contextlib
+        import chipmunk_amd  # noqa: F401
+        import chipmunk_amd.ops as ops_pkg
+        from chipmunk_amd.util import config as cfg
+        from chipmunk_amd.util.layer_counter import LayerCounter
+        from chipmunk_amd.util.step_cache import StepCache
+        from chipmunk_amd.modules import SparseDiffAttn
+        from chipmunk_amd import distributed as D
+
+        self.dev, self.rank, self.world, self.args = dev, rank, world, args
+        cfg.reset_to_base()
+        with contextlib.redirect_stdout(sys.stderr):
+            cfg.load_from_file(os.path.join(ROOT, "configs", "hunyuan_c3.yml"))
+        G = cfg.GLOBAL_CONFIG
+        G["world_size"] = world
+        G["step_caching"]["is_enabled"] = bool(args.step_caching)
+        if args.top_keys is not None:
+            G["attn"]["top_keys"] = args.top_keys
+        if args.offload:
+            G["offloading"]["keep_resident_if_fits"] = False
+        for item in filter(None, os.environ.get("BENCH_CFG", "").split(",")):
+            key, _, val = item.partition("=")
+            sec, _, name = key.partition(".")
+            G[sec][name] = {"true": True, "false": False}.get(val.lower(), val)
+        self.cfg = G
+        timer.keep_last_call = False
+        ops_pkg.csp_attn = timer.wrap("csp_128_attn", ops_pkg.csp_attn, _csp128_work)
+        ops_pkg.dense_attn = timer.wrap("dense_attn", ops_pkg.dense_attn, _dense_work)
+        ops_pkg.dense_colsum_attn = timer.wrap("dense_colsum_attn", ops_pkg.dense_colsum_attn, _colsum_work)
+
+        self.vid = tuple(int(x) for x in args.grid.split(","))
+        self.txt = 256
+        self.n_img = self.vid[0] * self.vid[1] * self.vid[2]
+        self.N = self.n_img + self.txt
+        self.H, self.D, self.HID, self.FFN = 24, 128, 3072, 12288
+        self.n_layers = args.layers or 60
+        assert self.H % world == 0 and self.n_img % world == 0, "head-parallel sharding needs world | 24 and world | tokens"
+        self.lh, self.ls = self.H // world, self.n_img // world
+        H, D, N = self.H, self.D, self.N
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        bf = dict(device=dev, dtype=torch.bfloat16)
+
+        self.sp = world > 1 or args.workload == "hunyuan_sp"
+        self.NSETS = 3   # rotating q,k,v sets (layer l uses set l mod 3): every layer's K/V comes from HBM, not from the
+        #                  256 MB Infinity Cache of the previous layer
+        if self.sp:
+            ch = args.sp_chunk_heads
+            self.n_chunks = self.lh // ch
+            self.pipe = D.HeadParallelPipeline(torch.distributed.group.WORLD if world > 1 else None, H, self.ls, self.txt, D,
+                                               torch.bfloat16, dev, chunk_heads=ch, overlap=not args.sp_no_overlap,
+                                               exchange=not args.sp_no_exchange)
+            if world > 1:
+                D.setup_dist(torch.distributed.group.WORLD, rank, world)
+            self.qkv_img = [torch.randn(3, 1, self.ls, H, D, generator=g, **bf) for _ in range(self.NSETS)]
+            gt = torch.Generator(device=dev).manual_seed(99)   # text rows are replicated: same on every rank
+            self.qkv_txt = [torch.randn(3, 1, self.txt, H, D, generator=gt, **bf) for _ in range(self.NSETS)]
+            self.rows = self.ls + (self.txt if rank == 0 else 0)
+        else:
+            self.n_chunks = 1
+            self.qkv = [[torch.randn(1, H, N, D, generator=g, **bf) for _ in range(3)] for _ in range(self.NSETS)]
+            self.rows = N
+        self.x = torch.randn(1, self.rows, self.HID, generator=g, **bf)
+        self.act = torch.nn.GELU(approximate="tanh")
+
+        self.layers = []
+        for li in range(self.n_layers):
+            layer_num, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
+            if self.sp:
+                attn = [SparseDiffAttn(layer_num, cc) for cc in D.chunk_counters(counter, self.n_chunks)]
+            else:
+                attn = [SparseDiffAttn(layer_num, counter)]
+            fc1 = torch.nn.Linear(self.HID, self.FFN, **bf)
+            fc2 = torch.nn.Linear(self.FFN, self.HID, **bf)
+            self.layers.append((attn, fc1, fc2))
+        self.counter = counter
+        self.step_cache = StepCache(counter)
+        heads_per_module = args.sp_chunk_heads if self.sp else H
+        t0 = time.perf_counter()
+        self.layers[0][0][0].initialize_static_mask(self.vid, self.txt, heads_per_module, dev)
+        torch.cuda.synchronize()
+        self.static_mask_s = time.perf_counter() - t0
+        self.step_events = []
+
+    # -- one denoise step: the reference's transformer loop (models.py:732-835) ---------------------------------
+    def step(self, i):
+        with torch.no_grad():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            kind = "skipped"
+            inference_step = self.counter.cur_inference_step
+            if self.step_cache.should_skip(inference_step):
+                self.step_cache.skip()
+            else:
+                kind = "full" if self.counter.should_do_full_attn_step() else "sparse"
+                if kind == "full":
+                    kind = "dense0" if inference_step == 0 else "mask"
+                L = len(self.layers)
+                y = None
+                for li, (attn, fc1, fc2) in enumerate(self.layers):
+                    for a in attn:                                         # wait for this block's cache ...
+                        if inference_step > 0 or li > 0:
+                            a.storage.load_async_wait()
+                    for a in self.layers[(li + 1) % L][0]:                 # ... start the next block's load
+                        a.storage.load_async()
+                    if self.sp:
+                        o_img, o_txt = self.pipe.run(self.qkv_img[li % self.NSETS], self.qkv_txt[li % self.NSETS], attn)
+                    else:
+                        q, k, v = self.qkv[li % self.NSETS]
+                        attn[0](q, k, v)
+                    y = fc2(self.act(fc1(self.x)))
+                self.step_cache.store(y)
+            self.step_events.append((inference_step, kind, ev))
+
+    def dense_step(self):
+        with torch.no_grad():
+            for li, (attn, fc1, fc2) in enumerate(self.layers):
+                q, k, v = self.qkv[li % self.NSETS]
+                torch.nn.functional.scaled_dot_product_attention(q, k, v)
+                fc2(self.act(fc1(self.x)))
+
+    def step_times(self):
+        """[(inference step, kind, seconds)] from the per-step events (each step's start to the next step's start)."""
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        end.synchronize()
+        evs = self.step_events + [(None, None, end)]
+        return [(evs[j][0], evs[j][1], evs[j][2].elapsed_time(evs[j + 1][2]) * 1e-3) for j in range(len(evs) - 1)]
+
+    def mean_counts(self):
+        import chipmunk_amd.ops as ops_pkg
+        a = self.layers[-1][0][0]
+        packed = a.storage.get_indices()
+        if packed is None:
+            return None
+        _, cnt = ops_pkg.mask_to_sorted_indices(packed, a.mask_shape[0], 128, 192)
+        return float(cnt.float().mean().item())
+
+    def leg_at(self, top_keys, sparse_steps=2):
+        """Re-mask every layer at another sparsity (one mask-recompute step), then time sparse steps."""
+        self.cfg["attn"]["top_keys"] = top_keys
+        c = self.counter
+        c.cur_inference_step, c.cur_layer, c.cur_layer_submodule, c.cur_model_invocation_per_step = 10, 0, 0, 0
+        was = self.cfg["step_caching"]["is_enabled"]
+        self.cfg["step_caching"]["is_enabled"] = False
+        self.step_events = []
+        for i in range(1 + sparse_steps):
+            self.step(10 + i)
+        times = self.step_times()
+        self.cfg["step_caching"]["is_enabled"] = was
+        mc = self.mean_counts()
+        return {"top_keys": top_keys, "mean_kept_keys": mc, "column_sparsity": None if mc is None else 1.0 - mc / self.N,
+                "mask_step_s": times[0][2], "sparse_step_s": sum(t for _, _, t in times[1:]) / max(1, len(times) - 1)}
+
+    def desc(self):
+        return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": HunyuanVideo 720x1280x129, {self.n_img} image + "
+                f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {self.n_layers} blocks (first 2 dense)",
+                "attention": "SparseDiffAttn, configs/hunyuan_c3.yml (full steps {0,1,10,40}, top 5% + 1% random + text columns, "
+                             "bit-packed masks)", "mlp": "dense fc2(gelu_tanh(fc1(x))) per block (hipBLASLt), as in the reference",
+                "attn_top_keys": self.cfg["attn"]["top_keys"], "step_caching": bool(self.cfg["step_caching"]["is_enabled"]),
+                "caches": "pinned-host offload" if self.args.offload else "resident in HBM (offloading.keep_resident_if_fits)",
+                "static_mask_init_s": round(self.static_mask_s, 2)}
+
+
+def cpu_baseline_hunyuan(n_layers, N, n_threads=None):
+    """the reference's dense eager path (F.scaled_dot_product_attention + fc2(act(fc1(x))), reference
+    modules/attn.py:193-194, modules/mlp.py:33-34) with PyTorch CPU on this box's host cores, on a bounded sample
+    (one head x 8 query groups against all keys; 1536 MLP rows), extrapolated to a full step.  The C oracle's dense
+    path on a smaller sample is timed beside it (kind 'port')."""
+    cores = n_threads or os.cpu_count()
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    H_s, N, rows_s = 2, 4352, 128
+    rows_a, rows_m = 8 * 192, 1536
+    q = torch.randn(1, 1, rows_a, 128, generator=g).to(torch.bfloat16)
+    k, v = [torch.randn(1, 1, N, 128, generator=g).to(torch.bfloat16) for _ in range(2)]
+    fc1 = torch.nn.Linear(3072, 12288, dtype=torch.bfloat16)
+    fc2 = torch.nn.Linear(12288, 3072, dtype=torch.bfloat16)
+    act = torch.nn.GELU(approximate="tanh")
+    x = torch.randn(1, rows_m, 3072, generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        torch.nn.functional.scaled_dot_product_attention(q[:, :, :192], k, v)   # thread pool / allocator warm-up
+        t0 = time.perf_counter()
+        torch.nn.functional.scaled_dot_product_attention(q, k, v)
+        t_attn = time.perf_counter() - t0
+        fc2(act(fc1(x[:, :128])))
+        t0 = time.perf_counter()
+        fc2(act(fc1(x)))
+        t_mlp = time.perf_counter() - t0
+    step_s = n_layers * (24 * (N / rows_a) * t_attn + (N / rows_m) * t_mlp)
+    out = {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "reference",
+           "sample": f"torch CPU bf16 (reference dense eager path): SDPA of 1 head x {rows_a} queries x {N} keys in {t_attn:.2f}s + "
+                     f"{rows_m} MLP rows in {t_mlp:.2f}s, extrapolated to 24 heads x {N} rows x {n_layers} blocks (dense)",
+           "what": "torch's CPU kernels are not reference code, but this IS the reference's CPU/eager path (SURVEY 8d)"}
+    try:
+        import oracle
+        qo = q[:, :, :192].contiguous()
+        t0 = time.perf_counter()
+        oracle.dense_attn(qo, k, v)
+        t_o = time.perf_counter() - t0
+        out["oracle_port"] = {"value": 1.0 / (n_layers * 24 * (N / 192) * t_o), "unit": "steps/s (attention only)",
+                              "cores": oracle.num_threads(), "sample": f"C oracle dense_attn, 1 head x 192 queries x {N} keys in {t_o:.2f}s"}
+    except Exception as e:  # the checker is optional for the baseline leg
+        out["oracle_port"] = {"error": str(e)[:200]}
+    return out
+
+
+def cpu_baseline_flux(n_layers):
+    """torch CPU dense eager path (reference modules/attn.py:193-194, modules/mlp.py:33-34) on a bounded
+    sample -- 4 of 24 heads of one layer's attention at N=4352 + 1024 MLP rows -- extrapolated to a full step; the C
+    oracle's dense path on a smaller sample beside it."""
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    H_s, N, rows_s = 4, 4352, 1024
     q, k, v = [torch.randn(1, H_s, N, 128, generator=g).to(torch.bfloat16) for _ in range(3)]
-    x = torch.randn(rows_s, 3072, generator=g).to(torch.bfloat16)
-    w1 = (torch.randn(12288, 3072, generator=g) * 0.02).to(torch.bfloat16)
-    b1 = torch.zeros(12288, dtype=torch.bfloat16)
-    w2 = (torch.randn(3072, 12288, generator=g) * 0.02).to(torch.bfloat16)
-    b2 = torch.zeros(3072, dtype=torch.bfloat16)
-    t0 = time.perf_counter()
-    oracle.dense_attn(q, k, v)
-    t_attn = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.dense_mlp(x, w1, b1, w2, b2)
-    t_mlp = time.perf_counter() - t0
+    fc1 = torch.nn.Linear(3072, 12288, dtype=torch.bfloat16)
+    fc2 = torch.nn.Linear(12288, 3072, dtype=torch.bfloat16)
+    act = torch.nn.GELU(approximate="tanh")
+    x = torch.randn(1, rows_s, 3072, generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        torch.nn.functional.scaled_dot_product_attention(q[:, :1], k[:, :1], v[:, :1])
+        t0 = time.perf_counter()
+        torch.nn.functional.scaled_dot_product_attention(q, k, v)
+        t_attn = time.perf_counter() - t0
+        fc2(act(fc1(x[:, :128])))
+        t0 = time.perf_counter()
+        fc2(act(fc1(x)))
+        t_mlp = time.perf_counter() - t0
     n_double = max(1, round(n_layers * 19 / 57))
     mlp_rows = n_double * 3840 + (n_layers - n_double) * 4352
     step_s = n_layers * t_attn * (24 / H_s) + t_mlp * (mlp_rows / rows_s)
-    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"oracle dense path: {H_s}/24 heads of one layer's attention (N=4352) in {t_attn:.1f}s + "
-                      f"{rows_s} MLP rows in {t_mlp:.1f}s, extrapolated to {n_layers} layers (dense, no sparsity)"}
+    out = {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "reference",
+           "sample": f"torch CPU bf16 (reference dense eager path): SDPA of {H_s}/24 heads (N=4352) in {t_attn:.2f}s + {rows_s} MLP rows "
+                     f"in {t_mlp:.2f}s, extrapolated to {n_layers} blocks (dense, no sparsity)"}
+    try:
+        import oracle
+        t0 = time.perf_counter()
+        oracle.dense_attn(q[:, :1].contiguous(), k[:, :1].contiguous(), v[:, :1].contiguous())
+        t_o = time.perf_counter() - t0
+        out["oracle_port"] = {"value": 1.0 / (n_layers * 24 * t_o), "unit": "steps/s (attention only)", "cores": oracle.num_threads(),
+                              "sample": f"C oracle dense_attn, 1 head at N=4352 in {t_o:.2f}s"}
+    except Exception as e:
+        out["oracle_port"] = {"error": str(e)[:200]}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -259,27 +524,43 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    if args.workload == "hunyuan_sp":
-        from chipmunk_amd.distributed import bench_hunyuan_sp
-        return bench_hunyuan_sp(args, rank, world, dev)
+    if args.workload == "auto":
+        args.workload = "hunyuan_c3" if world == 1 else "hunyuan_sp"
+    hunyuan = args.workload.startswith("hunyuan")
+    if args.steps is None:
+        args.steps = 20 if hunyuan else 50
+    if args.warmup is None:
+        args.warmup = 5 if hunyuan else 50
+    if args.dense_steps < 0:
+        args.dense_steps = 1 if hunyuan else 3
 
     timer = KernelTimer()
-    step, dense_step, desc = build_flux(dev, args.layers, timer)
+    if hunyuan:
+        wl = Hunyuan(dev, rank, world, args, timer)
+        step, desc = wl.step, wl.desc()
+        dense_step = (lambda i: wl.dense_step()) if not wl.sp else None
+        n_layers = wl.n_layers
+    else:
+        n_layers = args.layers or 57
+        step, dense_step, desc = build_flux(dev, n_layers, timer)
+        wl = None
 
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
     sync_all()
+    warm_times = wl.step_times() if wl else []
+    if wl:
+        wl.step_events = []
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -288,14 +569,37 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     if world > 1:
-        import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    timed_times = wl.step_times() if wl else []
+
+    extra = {}
+    if wl:
+        # ---- what the timed region was, per step kind; projection over the reference's whole 50-step schedule
+        kinds = {}
+        for _, kind, t in warm_times + timed_times:
+            kinds.setdefault(kind, []).append(t)
+        mean = {k: sum(v) / len(v) for k, v in kinds.items()}
+        mc = wl.mean_counts()
+        extra["timed_steps"] = {"inference_steps": [s for s, _, _ in timed_times],
+                                "kinds": {k: sum(1 for _, kk, _ in timed_times if kk == k) for k in kinds},
+                                "mean_step_s_by_kind (warm-up steps included)": {k: round(v, 4) for k, v in mean.items()}}
+        extra["mean_kept_keys_per_group"] = mc
+        extra["column_sparsity"] = None if mc is None else round(1.0 - mc / wl.N, 4)
+        if all(k in mean for k in ("dense0", "mask", "sparse")):
+            full50 = mean["dense0"] + 3 * mean["mask"] + 46 * mean["sparse"]
+            cached50 = mean["dense0"] + 3 * mean["mask"] + 21 * mean["sparse"]
+            extra["schedule_projection_50_steps"] = {
+                "what": "sum of measured mean step times over the shipped schedule: step 0 dense, steps 1/10/40 mask recompute, "
+                        "46 sparse steps; 'with_step_caching' drops the 25 skipped (all sparse) steps",
+                "seconds": round(full50, 2), "steps_per_s": 50.0 / full50,
+                "with_step_caching": {"seconds": round(cached50, 2), "steps_per_s": 50.0 / cached50}}
 
     dense_sps = None
-    if args.dense_steps > 0 and rank == 0 and world == 1:
-        dense_step(0)
+    if args.dense_steps > 0 and rank == 0 and world == 1 and dense_step is not None:
+        if not hunyuan:
+            dense_step(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.dense_steps):
@@ -303,28 +607,53 @@ def main():
         torch.cuda.synchronize()
         dense_sps = args.dense_steps / (time.perf_counter() - t0)
 
+    kernels = timer.summary() if rank == 0 else {}
+    roof = None
+    if kernels:
+        name, k = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
+        if hunyuan:   # ms-scale launches: the in-region HIP-event brackets ARE the launch durations (gaps ~ 10 us)
+            ms, flops, byts = k["avg_ms"], k["avg_flops"], k["avg_bytes"]
+        else:
+            ms, flops, byts = timer.probe(name)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFS, "traffic": pmc_traffic(name), "avg_launch_ms": ms,
+                "launches_in_timed_region": k["launches"], "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": byts, "hbm_frac_at_algorithmic_bytes": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if wl and not wl.sp and not args.no_82 and args.top_keys is None:
+        leg = wl.leg_at(0.17)
+        if "schedule_projection_50_steps" in extra:
+            m0 = extra["timed_steps"]["mean_step_s_by_kind (warm-up steps included)"]["dense0"]
+            tot = m0 + 3 * leg["mask_step_s"] + 46 * leg["sparse_step_s"]
+            leg["schedule_projection_50_steps"] = {"seconds": round(tot, 2), "steps_per_s": 50.0 / tot}
+        extra["sparsity_82_leg"] = leg
+
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()                      # nobody tears the communicator down while a peer is still timing
         dist.destroy_process_group()
     if rank != 0:
         return
-    value = world * args.steps / elapsed
-    desc["parallelism"] = f"independent replicas x{world} (no data-path collective)"
-    kernels = timer.summary()
-    roof = None
-    if kernels:
-        name, k = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
-        ms, flops, byts = timer.probe(name)
-        achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFS, "traffic": pmc_traffic(name), "avg_launch_ms": ms,
-                "in_region_avg_ms_incl_launch_gaps": k["avg_ms"], "algorithmic_flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": byts}
+    if hunyuan:
+        value = args.steps / elapsed
+        scaling = "strong" if wl.sp else "weak"
+        if wl.sp:
+            desc["parallelism"] = (f"head-parallel x{world} (attention: {wl.lh} heads/rank, all-to-all over RCCL pipelined in chunks of "
+                                   f"{args.sp_chunk_heads} head(s){'' if not args.sp_no_overlap else ', NO overlap'}); MLP sequence-parallel "
+                                   f"({wl.ls} rows/rank)")
+            desc["dist_world_size"] = world
+            desc["bytes_sent_per_rank_per_layer"] = wl.pipe.bytes_per_layer_sent
+            desc["exchange"] = not args.sp_no_exchange
+        else:
+            desc["parallelism"] = "single GPU"
+    else:
+        value = world * args.steps / elapsed
+        scaling = "weak"
+        desc["parallelism"] = f"independent replicas x{world} (no data-path collective)"
     line = {
         "metric": "DiT denoise steps/sec at fixed sparsity", "value": value, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": desc,
         "roofline": roof,
         "kernels": {n: {"launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
@@ -332,8 +661,17 @@ def main():
         "dense_gpu_comparator": None if dense_sps is None else {
             "value": dense_sps, "unit": "steps/s", "what": "same loop, F.scaled_dot_product_attention + nn.Linear (rocBLAS/hipBLASLt)",
             "sparse_over_dense": value / dense_sps},
-        "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.layers),
+        "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (
+            cpu_baseline_hunyuan(n_layers, wl.N) if hunyuan else cpu_baseline_flux(n_layers)),
     }
+    line.update(extra)
+    if dense_sps is not None and "schedule_projection_50_steps" in extra:
+        p50 = extra["schedule_projection_50_steps"]
+        p50["sparse_over_dense"] = p50["steps_per_s"] / dense_sps
+        p50["with_step_caching"]["sparse_over_dense"] = p50["with_step_caching"]["steps_per_s"] / dense_sps
+        if "sparsity_82_leg" in extra and "schedule_projection_50_steps" in extra["sparsity_82_leg"]:
+            q = extra["sparsity_82_leg"]["schedule_projection_50_steps"]
+            q["sparse_over_dense"] = q["steps_per_s"] / dense_sps
     print(json.dumps(line))
 
 

@@ -152,66 +152,157 @@ def group_parallel_attention(attn_rows: Callable, q_local: torch.Tensor, k_local
     return attn_rows(q_local, kv_all[0], kv_all[1])
 
 
-# ------------------------------------------------------------------------------------------------------ bench leg
-def bench_hunyuan_sp(args, rank: int, world: int, dev: torch.device) -> None:
-    """`bench.py --workload hunyuan_sp`: BASELINE.json configs[3] -- HunyuanVideo 720x1280x129 attention, heads sharded
-    over the ranks (all-to-all in, sparse attention on 24/G heads at 82 % column sparsity, all-to-all out), 60 layers
-    per step.  Strong scaling: the total work is fixed."""
-    import chipmunk_amd  # noqa: F401
-    n_img = args.seq or 118800
-    heads, d, layers = 24, 128, int(os.environ.get("CHIPMUNK_SP_LAYERS", "60"))
-    assert heads % world == 0 and n_img % world == 0
-    if world > 1:
-        setup_dist(dist.group.WORLD, rank, world)
-    ls, lh = n_img // world, heads // world
-    groups = (n_img + 191) // 192
-    keep = 128 * round(0.18 * n_img / 128)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    qkv = torch.randn(3, 1, ls, heads, d, device=dev, dtype=torch.bfloat16, generator=g)
-    inds = torch.empty(1, lh, groups, groups * 192, dtype=torch.int32, device=dev)
-    for h in range(lh):  # uniform-random sorted column sets of the exact target size (SURVEY 8d ii)
-        for g0 in range(0, groups, 64):
-            r = torch.rand(min(64, groups - g0), n_img, device=dev, generator=g)
-            inds[0, h, g0:g0 + r.shape[0], :keep] = r.topk(keep, dim=-1).indices.sort(dim=-1).values.to(torch.int32)
-    counts = torch.full((1, lh, groups), keep, dtype=torch.int32, device=dev)
+# ------------------------------------------------------------------------------------------ pipelined exchange
+class _NullCtx:
+    def __enter__(self):
+        return self
 
-    def layer():
-        q, k, v = all_to_all_collect_tokens(qkv)
-        o = torch.ops.chipmunk.csp_128_attn(q.contiguous(), k.contiguous(), v.contiguous(), inds, counts)
-        return all_to_all_collect_heads(o)
+    def __exit__(self, *a):
+        return False
 
-    def step():
-        for _ in range(layers):
-            layer()
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+class _ChunkCounter:
+    """View of the shared LayerCounter for ONE head chunk of a layer: all chunks of a layer see the same coordinates,
+    only the last chunk's ``increment`` moves the odometer (``SparseDiffAttn`` ticks it once per call)."""
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        flops = 98304.0 * keep * heads * groups * layers
-        print(json.dumps({
-            "metric": "DiT denoise steps/sec at fixed sparsity", "value": args.steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"hunyuan_sp: attention of HunyuanVideo 720x1280x129, {n_img} tokens, 24 heads, "
-                                   f"{layers} layers, 82% column sparsity (keep {keep}), head-parallel all-to-all",
-                       "parallelism": f"head-parallel x{world}"},
-            "roofline": {"kernel": "csp_128_attn", "bound": "mfma", "achieved": flops / (elapsed / args.steps) / 1e12 / world,
-                         "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / (elapsed / args.steps) / 1e12 / world / 2500.0,
-                         "traffic": None, "note": "per-GPU average over the whole step incl. all-to-all"},
-            "cpu_baseline": None}))
+    def __init__(self, counter, is_last: bool):
+        self._counter = counter
+        self._is_last = is_last
+
+    def __getattr__(self, name):
+        return getattr(self._counter, name)
+
+    def increment(self):
+        if self._is_last:
+            return self._counter.increment()
+        return self._counter.get_cur_coord()
+
+
+def chunk_counters(counter, n_chunks: int):
+    return [_ChunkCounter(counter, c == n_chunks - 1) for c in range(n_chunks)]
+
+
+class HeadParallelPipeline:
+    """Head-parallel exchange of one attention layer, pipelined over chunks of the rank's local heads.
+
+    The reference (``head_parallel.py:42-103``, ``attenion.py:229-292``) runs all-to-all(q,k,v) -> attention ->
+    all-to-all(o) back to back on one stream, so the exchange is fully exposed.  Every op on the sparse path is
+    independent per head, so here the rank's ``lh = h / G`` heads are split into chunks: chunk ``c + 1``'s q,k,v
+    all-to-all and chunk ``c - 1``'s output all-to-all run on a side (communication) stream while chunk ``c`` attends.
+    Only the first chunk's inbound and the last chunk's outbound exchange are exposed.  The dependency structure is the
+    real model's (nothing is prefetched across layers).  xGMI is point to point: every all-to-all is a single hop with all
+    7 links of the GPU busy; per chunk and rank ``3 * ls * d * 2`` bytes go to each peer.
+
+    All exchange buffers are allocated once (no allocator traffic across streams).  Works without a process group
+    (world 1: the exchange degenerates to the layout change) and on CPU tensors (gloo; no streams) for the tests.
+
+    ``attn_chunks[c](q, k, v) -> o``: attention of chunk ``c`` over ``[b, ch, s_img + s_txt, d]`` tensors.
+    """
+
+    def __init__(self, group, heads: int, ls: int, txt_len: int, d: int, dtype: torch.dtype, device: torch.device,
+                 chunk_heads: int = 1, batch: int = 1, overlap: bool = True, exchange: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.rank = dist.get_rank(group) if group is not None else 0
+        assert heads % self.world == 0, "the head count must divide by the world size (use group_parallel_attention otherwise)"
+        self.h, self.lh, self.ls, self.txt, self.d, self.b = heads, heads // self.world, ls, txt_len, d, batch
+        assert self.lh % chunk_heads == 0
+        self.ch = chunk_heads
+        self.n_chunks = self.lh // chunk_heads
+        self.s_img = ls * self.world
+        self.exchange = exchange and self.world > 1     # exchange=False: compute-only probe (measures exposed comm)
+        self.is_cuda = device.type == "cuda"
+        self.overlap = overlap and self.is_cuda
+        self.comm_stream = torch.cuda.Stream(device) if self.overlap else None
+        G, ch = self.world, self.ch
+        mk = lambda *shape: torch.empty(*shape, dtype=dtype, device=device)
+        # per chunk: send/recv slabs [G, ls, ch, b, 3, d]; the attention inputs [3, b, ch, s_img + txt, d]
+        self.send_in = [mk(G, ls, ch, batch, 3, d) for _ in range(self.n_chunks)]
+        self.recv_in = [mk(G, ls, ch, batch, 3, d) for _ in range(self.n_chunks)]
+        self.qkv = [mk(3, batch, ch, self.s_img + txt_len, d) for _ in range(self.n_chunks)]
+        self.send_out = [mk(G, ch, ls, batch, d) for _ in range(self.n_chunks)]
+        self.recv_out = [mk(G, ch, ls, batch, d) for _ in range(self.n_chunks)]
+        self.out_img = mk(batch, ls, heads, d)
+        self.out_txt_local = mk(batch, self.lh, txt_len, d)
+        self.bytes_per_layer_sent = (G - 1) * ls * self.lh * batch * 4 * d * self.send_in[0].element_size() if G > 1 else 0
+
+    def _stream(self, s):
+        return torch.cuda.stream(s) if s is not None else _NullCtx()
+
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        if self.exchange:
+            _all_to_all_single(out, inp, self.group)
+        elif self.world == 1:
+            out.copy_(inp)
+        # exchange=False at world > 1: buffers keep whatever they hold (timing probe only)
+
+    def _inbound(self, c: int, qkv_img: torch.Tensor, qkv_txt: torch.Tensor) -> None:
+        """qkv_img [3, b, ls, h, d] (local tokens, all heads), qkv_txt [3, b, txt, h, d] -> self.qkv[c]."""
+        G, ch, lh, ls, b, d = self.world, self.ch, self.lh, self.ls, self.b, self.d
+        # heads r*lh + c*ch .. + ch of every destination rank r
+        src = qkv_img.reshape(3, b, ls, G, lh, d)[:, :, :, :, c * ch:(c + 1) * ch]           # [3, b, ls, G, ch, d]
+        self.send_in[c].copy_(src.permute(3, 2, 4, 1, 0, 5))
+        self._a2a(self.recv_in[c], self.send_in[c])
+        dst = self.qkv[c][:, :, :, :self.s_img].reshape(3, b, ch, G, ls, d)
+        dst.copy_(self.recv_in[c].permute(4, 3, 2, 0, 1, 5))                                  # [3, b, ch, G(src), ls, d]
+        h0 = self.rank * lh + c * ch
+        self.qkv[c][:, :, :, self.s_img:].copy_(qkv_txt[:, :, :, h0:h0 + ch].permute(0, 1, 3, 2, 4))
+
+    def _outbound(self, c: int, o: torch.Tensor) -> None:
+        """o [b, ch, s_img + txt, d] -> image rows back to token sharding (heads r*lh + c*ch.. of source rank r)."""
+        G, ch, lh, ls, b, d = self.world, self.ch, self.lh, self.ls, self.b, self.d
+        self.send_out[c].copy_(o[:, :, :self.s_img].reshape(b, ch, G, ls, d).permute(2, 1, 3, 0, 4))
+        self._a2a(self.recv_out[c], self.send_out[c])
+        dst = self.out_img.reshape(b, ls, G, lh, d)[:, :, :, c * ch:(c + 1) * ch]             # [b, ls, G, ch, d]
+        dst.copy_(self.recv_out[c].permute(3, 2, 0, 1, 4))
+        self.out_txt_local[:, c * ch:(c + 1) * ch].copy_(o[:, :, self.s_img:])
+
+    @torch.compiler.disable
+    def run(self, qkv_img: torch.Tensor, qkv_txt: torch.Tensor, attn_chunks) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Returns ``(o_img [b, ls, h*d], o_txt [b, txt, h*d])``: image rows token-sharded, text rows replicated."""
+        assert len(attn_chunks) == self.n_chunks
+        n = self.n_chunks
+        comm = self.comm_stream
+        cur = torch.cuda.current_stream() if self.is_cuda else None
+        if comm is not None:
+            comm.wait_stream(cur)            # the layer's inputs are ready; the previous layer's readers are done
+        ev_in = [None] * n
+        ev_out = [None] * n
+
+        def inbound(c):
+            with self._stream(comm):
+                self._inbound(c, qkv_img, qkv_txt)
+                if comm is not None:
+                    ev_in[c] = comm.record_event()
+
+        def outbound(c, o):
+            with self._stream(comm):
+                if comm is not None:
+                    comm.wait_event(ev_out[c])
+                    o.record_stream(comm)
+                self._outbound(c, o)
+
+        # comm-stream order: in(0), in(1), out(0), in(2), out(1), ..., out(n-1): chunk c+1 arrives while chunk c attends
+        inbound(0)
+        for c in range(n):
+            if c + 1 < n:
+                inbound(c + 1)
+            if comm is not None:
+                cur.wait_event(ev_in[c])
+            q, k, v = self.qkv[c][0], self.qkv[c][1], self.qkv[c][2]
+            o = attn_chunks[c](q, k, v)
+            if comm is not None:
+                ev_out[c] = cur.record_event()
+            outbound(c, o)
+        if comm is not None:
+            cur.wait_stream(comm)
+        b = self.b
+        o_txt = self.out_txt_local
+        if self.exchange:
+            gathered = all_gather_into_tensor(o_txt.reshape(1, *o_txt.shape), self.group)     # [G, b, lh, txt, d]
+            o_txt = gathered.permute(1, 3, 0, 2, 4).reshape(b, self.txt, self.h * self.d)
+        else:
+            o_txt = o_txt.permute(0, 2, 1, 3).reshape(b, self.txt, self.lh * self.d)
+            if self.world > 1:
+                o_txt = o_txt.repeat(1, 1, self.world)
+        return self.out_img.reshape(b, self.ls, self.h * self.d), o_txt

@@ -64,6 +64,29 @@ def _worker(rank, world, port, ret):
         o = D.group_parallel_attention(attn, ql, kl, vl)
         full_o = F.scaled_dot_product_attention(*[full[k][0].permute(0, 2, 1, 3) for k in "qkv"])
         torch.testing.assert_close(o, full_o[:, :, rank * ls:(rank + 1) * ls], rtol=1e-5, atol=1e-5)
+
+        # ---- pipelined exchange (chunks of local heads): same result as head_parallel_attention, for 1 and 2 heads per chunk
+        a2, lh2 = 8, 8 // world
+        g2 = torch.Generator().manual_seed(5)
+        img_full = torch.randn(3, b, s_img, a2, d, generator=g2)
+        txt_full = torch.randn(3, b, s_txt, a2, d, generator=g2)
+        qf, kf, vf = [torch.cat([img_full[i], txt_full[i]], dim=1).permute(0, 2, 1, 3) for i in range(3)]
+        ref2 = F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3)            # [b, s, a2, d]
+        for ch in (1, 2, 4):
+            pipe = D.HeadParallelPipeline(dist.group.WORLD, a2, ls, s_txt, d, torch.float32, torch.device("cpu"), chunk_heads=ch)
+            seen = []
+
+            def mk(c):
+                def f(q, k, v):
+                    seen.append((c, tuple(q.shape)))
+                    return F.scaled_dot_product_attention(q, k, v)
+                return f
+            for rep in range(2):   # buffers are reused across layers
+                o_img, o_txt = pipe.run(img_full[:, :, rank * ls:(rank + 1) * ls].contiguous(), txt_full, [mk(c) for c in range(lh2 // ch)])
+                torch.testing.assert_close(o_img, ref2[:, rank * ls:(rank + 1) * ls].reshape(b, ls, a2 * d), rtol=1e-5, atol=1e-5)
+                torch.testing.assert_close(o_txt, ref2[:, s_img:].reshape(b, s_txt, a2 * d), rtol=1e-5, atol=1e-5)
+            assert seen[0] == (0, (b, ch, s_img + s_txt, d)) and len(seen) == 2 * (lh2 // ch)
+            assert pipe.bytes_per_layer_sent == (world - 1) * ls * lh2 * b * 4 * d * 4
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -86,3 +109,24 @@ def test_single_process_paths_without_group():
     o = torch.randn(1, 4, 8, 16)
     assert torch.equal(D.all_to_all_collect_heads(o), o.permute(0, 2, 1, 3).reshape(1, 8, 64))
     assert D.all_gather(o) is o
+
+
+def test_pipeline_without_group_and_chunk_counter(fresh_config):
+    from chipmunk_amd import distributed as D
+    from chipmunk_amd.util.layer_counter import LayerCounter
+    b, a, d, s_img, s_txt = 1, 4, 16, 12, 3
+    g = torch.Generator().manual_seed(1)
+    img, txt = torch.randn(3, b, s_img, a, d, generator=g), torch.randn(3, b, s_txt, a, d, generator=g)
+    pipe = D.HeadParallelPipeline(None, a, s_img, s_txt, d, torch.float32, torch.device("cpu"), chunk_heads=2)
+    o_img, o_txt = pipe.run(img, txt, [lambda q, k, v: F.scaled_dot_product_attention(q, k, v)] * 2)
+    q, k, v = [torch.cat([img[i], txt[i]], dim=1).permute(0, 2, 1, 3) for i in range(3)]
+    ref = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3)
+    torch.testing.assert_close(o_img, ref[:, :s_img].reshape(b, s_img, a * d), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(o_txt, ref[:, s_img:].reshape(b, s_txt, a * d), rtol=1e-5, atol=1e-5)
+    # chunk counters: every chunk of a layer sees the same coordinates; only the last one moves the odometer
+    _, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
+    LayerCounter.build_for_layer(is_attn_sparse=True)
+    views = D.chunk_counters(counter, 3)
+    assert [v.increment() for v in views] == [(0, 0, 0)] * 3
+    assert counter.get_cur_coord() == (0, 1, 0) and views[0].cur_layer == 1
+    assert views[1].should_do_full_attn_step() == counter.should_do_full_attn_step()
