@@ -277,7 +277,7 @@ class Hunyuan:
         from chipmunk_amd.util.layer_counter import LayerCounter
         from chipmunk_amd.util.step_cache import StepCache
         from chipmunk_amd.modules import SparseDiffAttn
-        from chipmunk_amd import distributed as D
+        from chipmunk_amd import distributed as dist_mod
 
         self.dev, self.rank, self.world, self.args = dev, rank, world, args
         cfg.reset_to_base()
@@ -318,11 +318,11 @@ class Hunyuan:
         if self.sp:
             ch = args.sp_chunk_heads
             self.n_chunks = self.lh // ch
-            self.pipe = D.HeadParallelPipeline(torch.distributed.group.WORLD if world > 1 else None, H, self.ls, self.txt, D,
+            self.pipe = dist_mod.HeadParallelPipeline(torch.distributed.group.WORLD if world > 1 else None, H, self.ls, self.txt, D,
                                                torch.bfloat16, dev, chunk_heads=ch, overlap=not args.sp_no_overlap,
                                                exchange=not args.sp_no_exchange)
             if world > 1:
-                D.setup_dist(torch.distributed.group.WORLD, rank, world)
+                dist_mod.setup_dist(torch.distributed.group.WORLD, rank, world)
             self.qkv_img = [torch.randn(3, 1, self.ls, H, D, generator=g, **bf) for _ in range(self.NSETS)]
             gt = torch.Generator(device=dev).manual_seed(99)   # text rows are replicated: same on every rank
             self.qkv_txt = [torch.randn(3, 1, self.txt, H, D, generator=gt, **bf) for _ in range(self.NSETS)]
@@ -338,7 +338,7 @@ class Hunyuan:
         for li in range(self.n_layers):
             layer_num, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
             if self.sp:
-                attn = [SparseDiffAttn(layer_num, cc) for cc in D.chunk_counters(counter, self.n_chunks)]
+                attn = [SparseDiffAttn(layer_num, cc) for cc in dist_mod.chunk_counters(counter, self.n_chunks)]
             else:
                 attn = [SparseDiffAttn(layer_num, counter)]
             fc1 = torch.nn.Linear(self.HID, self.FFN, **bf)

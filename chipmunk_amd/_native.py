@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libchipmunk_hip.so")
 
 # every symbol include/chipmunk_hip.h declares (tests/test_abi.py checks this list against the header)
 SYMBOLS = [
-    "chipmunk_last_error", "chipmunk_abi_version", "chipmunk_set_option",
+    "chipmunk_last_error", "chipmunk_abi_version", "chipmunk_set_option", "chipmunk_set_random_seed",
     "chipmunk_csp_attn", "chipmunk_csp_attn_out", "chipmunk_csp_128_attn", "chipmunk_dense_attn", "chipmunk_dense_colsum_attn",
     "chipmunk_csp_mlp_mm1", "chipmunk_csp_mlp_mm1_scatter", "chipmunk_csp_mlp_mm1_fp8", "chipmunk_csp_mlp_mm2_and_scatter_add", "chipmunk_csp_scatter_add", "chipmunk_csp_mlp_mm2",
     "chipmunk_topk_indices", "chipmunk_topk_delta_indices", "chipmunk_topk_mask", "chipmunk_mask_to_indices", "chipmunk_mask_to_sorted_indices", "chipmunk_packed_mask_to_indices", "chipmunk_copy_indices",
@@ -50,3 +50,9 @@ def check(rc: int, what: str) -> None:
 
 def set_option(name: str, value: int) -> None:
     check(lib().chipmunk_set_option(name.encode(), int(value)), "chipmunk_set_option")
+
+
+def manual_seed(seed: int) -> None:
+    """Restart the random-key sequence of topk_indices / topk_mask (`random_amount` > 0): same seed + same launch order
+    = same random columns.  Without a call the sequence starts from a fixed default seed."""
+    check(lib().chipmunk_set_random_seed(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)), "chipmunk_set_random_seed")

@@ -29,6 +29,31 @@ extern "C" int chipmunk_set_option(const char *name, int value) {
     return CHIPMUNK_ERR_INVALID;
 }
 
+// ---- random keys: per-launch salt ----
+// topk_indices / topk_delta_indices / topk_mask add `random_amount` of the columns through a counter-based hash of
+// (row, column, salt).  The salt is splitmix64(seed + launch counter): every launch -- layer, step, generation -- draws
+// a different set (the reference reseeds cuRAND per call, topk_indices.cu:47-49, and calls torch.randint per layer,
+// modules/attn.py:77).  chipmunk_set_random_seed(seed) restarts the sequence: same seed + same launch order = same sets.
+// A launch captured into a hipGraph replays with the salt it was captured with; the kernels also mix in the first
+// element of each row, so replays on new data still draw new sets.
+#include <atomic>
+namespace {
+std::atomic<uint64_t> g_rng_seed{0x243F6A8885A308D3ull};
+std::atomic<uint64_t> g_rng_counter{0};
+}
+uint32_t chipmunk_next_random_salt() {
+    uint64_t z = g_rng_seed.load(std::memory_order_relaxed) + 0x9E3779B97F4A7C15ull * (g_rng_counter.fetch_add(1) + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 16);
+}
+extern "C" int chipmunk_set_random_seed(uint64_t seed) {
+    g_rng_seed.store(seed * 0xD6E8FEB86659FD93ull + 0x243F6A8885A308D3ull);
+    g_rng_counter.store(0);
+    return CHIPMUNK_OK;
+}
+
 // ---- per-(device, stream) scratch: schedule arrays, split-K partials, arrival tickets ----
 // Grow-only, zero-filled when (re)allocated, contents persist between launches (kernels that use tickets leave them at
 // zero).  Keyed by stream so that launches on different streams never share a buffer; launches on one stream are

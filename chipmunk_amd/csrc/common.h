@@ -142,6 +142,7 @@ inline int device_cu_count() {
 // ---- host-side error plumbing (thread-local message, see chipmunk_last_error) ----
 void chipmunk_set_error(const char *fmt, ...);
 int chipmunk_get_option(const char *name);
+uint32_t chipmunk_next_random_salt();  // per-launch salt of the random-key hash (capi.hip)
 // zero-initialised, grow-only device scratch owned by the library, one per (device, stream); nullptr on failure
 void *chipmunk_scratch(hipStream_t stream, size_t bytes);
 #define CM_CHECK(cond, ...)                    \

@@ -206,6 +206,7 @@ struct TopkParams {
     int32_t *counts;
     int rows, cols, multiple_of;
     float quantile, random_amount;
+    uint32_t salt;  // per-launch value (host counter mixed with the seed, see chipmunk_next_random_salt)
 };
 
 template <typename T>
@@ -226,9 +227,12 @@ __device__ __forceinline__ float round_to<_Float16>(float x) { return (float)(_F
 template <>
 __device__ __forceinline__ float round_to<float>(float x) { return x; }
 
-// counter-based uniform in [0,1): replaces cuRAND Philox of topk_indices.cu:46-49,108 (RNG streams cannot match)
-__device__ __forceinline__ float hash_uniform(uint32_t row, uint32_t col) {
-    uint32_t x = row * 0x9E3779B9u ^ (col + 0x7F4A7C15u) * 0x85EBCA6Bu;
+// counter-based uniform in [0,1): replaces cuRAND Philox of topk_indices.cu:46-49,108 (RNG streams cannot match).
+// `salt` changes with every launch (host counter + seed) and with the row's data (its first element, as the reference
+// seeds cuRAND from the first activation word, topk_indices.cu:47-49): the random keys exist to refresh stale cache
+// columns over time, so the chosen set must differ between layers, steps and generations.
+__device__ __forceinline__ float hash_uniform(uint32_t row, uint32_t col, uint32_t salt) {
+    uint32_t x = (row * 0x9E3779B9u ^ (col + 0x7F4A7C15u) * 0x85EBCA6Bu) + salt * 0xC2B2AE35u;
     x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
         else return b;
     };
 
+    const uint32_t salt = p.salt ^ (__float_as_uint(load_as_float<T>(x, 0)) * 0x27D4EB2Fu);
     if (p.quantile == 0.f) {  // keep everything (topk_indices.cu:51-59)
         if constexpr (DELTA)
             for (int c = tid; c < cols; c += 1024) xc[c] = x[c];
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
             bool keep = false;
             if (c < cols) {
                 keep = v[j] >= thr;
-                if (!keep && p.random_amount > 0.f) keep = hash_uniform(row, c) < p.random_amount;
+                if (!keep && p.random_amount > 0.f) keep = hash_uniform(row, c, salt) < p.random_amount;
                 if (!keep) my_last_invalid = c;  // ascending c per thread => ends as the last rejected column
             }
             const unsigned long long bal = __ballot(keep);
@@ -519,6 +524,7 @@ struct TopkMaskParams {
     int64_t cs_stride, stat_stride;
     int rows, n, k, stat_rows;
     float random_amount;
+    uint32_t salt;           // per-launch value, see chipmunk_next_random_salt
 };
 
 __device__ __forceinline__ uint32_t bf16_key(uint32_t u) {  // monotone bf16 bits -> u16 (larger value = larger key)
@@ -653,6 +659,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     uint8_t *out = p.mask + (int64_t)row * n;
     const uint8_t *st = p.stat ? p.stat + (int64_t)(row % p.stat_rows) * p.stat_stride : nullptr;
     const bool rnd = active && p.random_amount > 0.f;
+    const uint32_t salt = p.salt ^ ((uint32_t)x[0] * 0x27D4EB2Fu);
     const int nsteps = (n + 4095) / 4096;
 #pragma unroll 2
     for (int j = 0; j < nsteps; ++j) {
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
             const bool tie = kv == thr && tie_budget > 0 && c + e < n;
             tie_budget -= tie ? 1 : 0;
             keep = keep || tie;
-            if (rnd && !keep) keep = hash_uniform(row, c + e) < p.random_amount;
+            if (rnd && !keep) keep = hash_uniform(row, c + e, salt) < p.random_amount;
             keep = keep || ((sb >> (8 * e)) & 0xffu) != 0;
             bytes |= (keep ? 1u : 0u) << (8 * e);
         }
@@ -713,7 +720,8 @@ static int launch_topk(const void *activation, void *cache, int dtype, int32_t *
     CM_CHECK(multiple_of > 0, "topk_indices: multiple_of must be positive");
     CM_CHECK(sparsity_amount >= 0.0 && sparsity_amount <= 1.0, "topk_indices: sparsity_amount must be in [0,1]");
     if (rows == 0) return CHIPMUNK_OK;
-    TopkParams p = {activation, cache, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount};
+    TopkParams p = {activation, cache, indices, counts, rows, cols, multiple_of, (float)sparsity_amount, (float)random_amount,
+                    random_amount > 0.0 ? chipmunk_next_random_salt() : 0u};
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TOPK(T)                                                                                           \
     do {                                                                                                         \
@@ -813,7 +821,8 @@ extern "C" int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void 
     CM_CHECK(random_amount >= 0.0 && random_amount <= 1.0, "topk_mask: random_amount must be in [0,1]");
     if (rows == 0) return CHIPMUNK_OK;
     TopkMaskParams p = {(const uint16_t *)cs, (const uint8_t *)static_mask, (const uint8_t *)group_flags, (uint8_t *)mask,
-                        cs_stride, static_stride, rows, n, k, static_mask ? static_rows : 1, (float)random_amount};
+                        cs_stride, static_stride, rows, n, k, static_mask ? static_rows : 1, (float)random_amount,
+                        random_amount > 0.0 ? chipmunk_next_random_salt() : 0u};
     hipStream_t s = (hipStream_t)stream;
     const bool aligned = n % 4 == 0 && (((uintptr_t)cs) & 7) == 0 && (cs_stride * 2) % 8 == 0 && (((uintptr_t)mask) & 3) == 0 &&
                          (!static_mask || ((((uintptr_t)static_mask) & 3) == 0 && static_stride % 4 == 0));

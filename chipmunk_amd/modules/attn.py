@@ -12,7 +12,7 @@ Per (inference step, layer) one of four things happens (reference ``_fast_attent
 Two index styles, selected by the config exactly as in the reference:
 ``should_compress_indices`` (HunyuanVideo/Wan): a bit-packed bool mask is stored and turned into (indices, counts)
 every step; otherwise (FLUX) ``torch.topk`` indices are stored directly and the in-place kernel is used.
-With ``attn.fused_packed_mask_to_indices`` (default on, not in the reference) the bit-packed mask goes straight to the
+With ``attn.fused_packed_mask_to_indices`` (on in BASE_CONFIG, not in the reference) the bit-packed mask goes straight to the
 indices kernel instead of through a materialised bool mask -- same indices, 8x less traffic.
 """
 from __future__ import annotations
@@ -90,8 +90,8 @@ class SparseDiffAttn(nn.Module):
         if cfg["should_compress_indices"]:
             packed = self.storage.get_indices()
             shape = self.mask_shape[self.layer_counter.cur_model_invocation_per_step]
-            if cfg.get("fused_packed_mask_to_indices", False) and packed.is_cuda and shape[-1] % 8 == 0:
-                if cfg.get("sorted_indices", False):
+            if cfg.get("fused_packed_mask_to_indices", True) and packed.is_cuda and shape[-1] % 8 == 0:
+                if cfg.get("sorted_indices", True):
                     return ops.mask_to_sorted_indices(packed, shape, multiple_of, bm)
                 return ops.packed_mask_to_indices(packed, shape, multiple_of, bm)
             return ops.mask_to_indices(ops.bitunpack(packed, shape), multiple_of, bm)
@@ -133,7 +133,7 @@ class SparseDiffAttn(nn.Module):
                     packed, mask_shape = ops.bitpack(mask)
                     self.mask_shape[self.layer_counter.cur_model_invocation_per_step] = mask_shape
                     self.storage.set_indices(packed)
-                    if mask.is_cuda and cfg.get("fused_packed_mask_to_indices", False) and cfg.get("sorted_indices", False):
+                    if mask.is_cuda and cfg.get("fused_packed_mask_to_indices", True) and cfg.get("sorted_indices", True):
                         inds, counts = ops.mask_to_sorted_indices(mask, mask.shape, multiple_of, bm)
                     else:
                         inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
@@ -168,9 +168,13 @@ class SparseDiffAttn(nn.Module):
         o = self.storage.get_out_cache()
         if do_padding:
             return o + ops.csp_attn(q, k, v, inds, counts)
-        if o.is_cuda and cfg.get("fused_residual", True) and not self.storage.out_cache.is_offload_enabled:
+        # Is `o` the persistent cache itself, or a pipeline slot that the next load overwrites from the host copy?  The
+        # reference decides on the config flag (attn.py:186-188) because there a flagged tensor always lives on the host;
+        # here a flagged tensor may stay resident (offloading.keep_resident_if_fits), so ask the storage.
+        persistent = self.storage.out_cache.is_resident()
+        if o.is_cuda and cfg.get("fused_residual", True) and persistent:
             return ops.csp_attn_out(q, k, v, o, inds, counts, 1)  # cache + delta in one kernel, cache untouched
-        if not self.storage.out_cache.is_offload_enabled:
+        if persistent:
             o = o.clone()  # the kernel accumulates in place and the cache must survive (reference attn.py:186-188)
         ops.csp_attn_inplace(q, k, v, o, inds, counts, 1)
         return o

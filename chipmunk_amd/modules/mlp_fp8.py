@@ -53,6 +53,43 @@ class F8Linear(nn.Module):
         for name in ("scale", "input_scale", "scale_reciprocal", "input_scale_reciprocal"):
             self.register_buffer(name, None)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Quantise on load (reference mlp_fp8.py:67-168).  Two checkpoint forms are accepted: a float ``weight`` of the
+        layer's shape (quantised here), or an already quantised layer -- ``float8_data`` (the reference's buffer name) or
+        an fp8 ``weight`` -- with its ``scale`` / ``scale_reciprocal`` (and optionally the frozen input scale)."""
+        sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        shape = (self.out_features, self.in_features)
+        if "weight" not in sd and "float8_data" not in sd:
+            raise RuntimeError("Weight tensor not found or has incorrect shape in state dict")
+        fp8 = sd.get("float8_data")
+        if fp8 is None and sd["weight"].dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+            fp8 = sd["weight"]
+        if "bias" in sd:
+            self._parameters["bias"] = nn.Parameter(sd["bias"], requires_grad=False)
+        if fp8 is None:
+            if tuple(sd["weight"].shape) != shape:
+                raise RuntimeError(f"Weight tensor not found or has incorrect shape in state dict: {sd.keys()}")
+            self._parameters["weight"] = nn.Parameter(sd["weight"], requires_grad=False)
+            self.weight_initialized = False
+            self.quantize_weight()
+            return
+        if tuple(fp8.shape) != shape or "scale" not in sd:
+            raise RuntimeError(f"Weight tensor not found or has incorrect shape in state dict: {sd.keys()}")
+        self._parameters["weight"] = nn.Parameter(fp8.to(self.float8_dtype), requires_grad=False)
+        self.weight_initialized = True
+        self.scale = sd["scale"].float()
+        self.scale_reciprocal = sd["scale_reciprocal"].float() if "scale_reciprocal" in sd else self.scale.reciprocal()
+        if "input_scale" in sd and "input_scale_reciprocal" in sd:
+            self.input_scale = sd["input_scale"].float()
+            self.input_scale_reciprocal = sd["input_scale_reciprocal"].float()
+            self.input_scale_initialized = True
+            self.trial_index = self.num_scale_trials
+        else:                                   # calibrate the input scale again over the first calls
+            self.input_scale_initialized = False
+            self.trial_index = 0
+            self.input_amax_trials = torch.zeros(self.num_scale_trials, requires_grad=False, dtype=torch.float32,
+                                                 device=self.weight.device)
+
     # kept as methods too: the reference exposes them on the instance (mlp_fp8.py:191-195)
     def amax_to_scale(self, amax, max_val):
         return amax_to_scale(amax, max_val)
@@ -124,23 +161,44 @@ class F8Linear(nn.Module):
 @torch.inference_mode()
 def recursive_swap_linears(model: nn.Module, float8_dtype=torch.float8_e4m3fn,
                            input_float8_dtype=torch.float8_e4m3fn, parent_name: Optional[str] = None,
-                           quantize_modulation: bool = True, ignore_keys=()) -> None:
-    """Replace every ``nn.Linear`` below ``model`` by an ``F8Linear`` in place (reference mlp_fp8.py:295-350)."""
+                           quantize_modulation: bool = True, ignore_keys=("modulation",)) -> None:
+    """Replace the ``nn.Linear`` children below ``model`` by ``F8Linear`` in place, with the reference's exclusions
+    (mlp_fp8.py:295-350): children named in ``ignore_keys``, children whose name contains ``mod`` (the modulation
+    layers -- skipped regardless of ``quantize_modulation``, exactly as the reference does), and ``fc2`` of a sparse
+    image MLP (child ``"2"`` of an ``nn.Sequential`` named ``img_mlp``) while ``mlp.is_enabled``: the sparse step's
+    GEMM2 gathers bf16 rows of ``fc2.weight.T``."""
+    from ..util.config import GLOBAL_CONFIG
     for name, child in list(model.named_children()):
-        full = name if parent_name is None else f"{parent_name}.{name}"
-        if any(k in full for k in ignore_keys):
+        if name in ignore_keys or "mod" in name:
+            continue
+        if (isinstance(model, nn.Sequential) and str(name) == "2" and isinstance(child, nn.Linear)
+                and parent_name == "img_mlp" and GLOBAL_CONFIG["mlp"]["is_enabled"]):
+            print("skipping fc2 of sparse img mlp")
             continue
         if isinstance(child, nn.Linear) and not isinstance(child, F8Linear):
-            if not quantize_modulation and "mod" in full.lower():
-                continue
             setattr(model, name, F8Linear.from_linear(child, float8_dtype, input_float8_dtype))
         else:
-            recursive_swap_linears(child, float8_dtype, input_float8_dtype, full, quantize_modulation, ignore_keys)
+            recursive_swap_linears(child, float8_dtype, input_float8_dtype, name, quantize_modulation, ignore_keys)
 
 
 @torch.inference_mode()
-def quantize_fp8(model: nn.Module, float8_dtype=torch.float8_e4m3fn, input_float8_dtype=torch.float8_e4m3fn,
-                 quantize_modulation: bool = True, ignore_keys=()) -> nn.Module:
-    """Swap the model's linear layers to fp8 (reference mlp_fp8.py:352-400)."""
-    recursive_swap_linears(model, float8_dtype, input_float8_dtype, None, quantize_modulation, ignore_keys)
-    return model
+def quantize_fp8(flow_model: nn.Module, device=torch.device("cuda"), float8_dtype=torch.float8_e4m3fn,
+                 input_float8_dtype=torch.float8_e4m3fn, quantize_modulation: bool = True) -> nn.Module:
+    """Move the transformer blocks to ``device`` one at a time and swap their linear layers to fp8 (reference
+    mlp_fp8.py:352-400; called as ``quantize_fp8(model, device=device)`` by examples/flux/src/flux/util.py:350).
+    The reference walks ``flow_model.double_blocks`` and ``.single_blocks``; a module without those attributes is
+    treated as one block."""
+    blocks = []
+    for attr in ("double_blocks", "single_blocks"):
+        if hasattr(flow_model, attr):
+            blocks.extend(getattr(flow_model, attr))
+    if not blocks:
+        blocks = [flow_model]
+    for module in blocks:
+        module.to(device)
+        module.eval()
+        recursive_swap_linears(module, float8_dtype=float8_dtype, input_float8_dtype=input_float8_dtype,
+                               quantize_modulation=quantize_modulation)
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    return flow_model

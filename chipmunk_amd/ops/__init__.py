@@ -1,7 +1,7 @@
 """Operator wrappers with the reference's names (``src/chipmunk/ops/__init__.py:1-7``)."""
 from .mlp import run_e2e as mlp
 from .indexed_io import (copy_indices, topk_indices, mask_to_indices, scatter_add, packed_mask_to_indices,
-                         mask_to_sorted_indices, topk_mask)
+                         mask_to_sorted_indices, topk_mask, manual_seed)
 from .attn import csp_attn, csp_attn_inplace, csp_attn_out, dense_attn, dense_colsum_attn
 from .patch import patchify, unpatchify, patchify_rope
 from .bitpack import bitpack, bitunpack
@@ -9,6 +9,6 @@ from . import voxel
 
 __all__ = ["mlp", "copy_indices", "topk_indices", "mask_to_indices", "scatter_add", "csp_attn", "dense_attn",
            "dense_colsum_attn", "patchify", "unpatchify", "patchify_rope", "bitpack", "bitunpack",
-           "packed_mask_to_indices", "mask_to_sorted_indices", "csp_attn_inplace", "csp_attn_out", "topk_mask", "voxel"]
+           "packed_mask_to_indices", "mask_to_sorted_indices", "csp_attn_inplace", "csp_attn_out", "topk_mask", "voxel", "manual_seed"]
 
 from . import _fake  # noqa: E402,F401  shape-only ("fake") kernels so torch.compile can trace through the ops

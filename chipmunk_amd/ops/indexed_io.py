@@ -45,3 +45,10 @@ def topk_mask(cs: torch.Tensor, k: int, random_amount: float = 0.0, groups: Opti
     come from the top-k part (ties at the k-th value broken deterministically); the random part is a counter-based
     hash, so only ``random_amount = 0`` is comparable bit for bit with the torch chain."""
     return torch.ops.chipmunk.topk_mask(cs, k, random_amount, groups, static_mask)
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the random-key hash used when ``random_amount`` / ``rk`` > 0 (see ``include/chipmunk_hip.h``:
+    ``chipmunk_set_random_seed``).  Every launch draws a different set; the same seed and launch order reproduce a run."""
+    from .._native import manual_seed as _seed
+    _seed(seed)

@@ -69,7 +69,9 @@ BASE_CONFIG: Dict[str, Any] = {
     },
 }
 
-# Keys that do not exist in the reference.  They default to the reference's behaviour.
+# Keys that do not exist in the reference.  `keep_resident_if_fits` defaults to the reference's behaviour (off); the
+# fusion switches default to ON -- each fused path produces the results of the reference's op sequence (tests compare
+# them) -- and can be switched off per key to run the reference's exact op sequence on the GPU.
 AMD_EXTRA_KEYS: Dict[str, Any] = {
     # 288 GB of HBM3E holds the whole per-layer cache of HunyuanVideo (60 x 0.95 GB): when set, tensors whose offload
     # flag is on stay resident on the device as long as `hbm_budget_gb` is not exceeded.

@@ -67,7 +67,6 @@ class MaybeOffloadedTensor:
         self.gpu_tensor: List[Optional[torch.Tensor]] = [None] * n_inv  # resident path
         self.real_shape: List[Optional[torch.Size]] = [None] * n_inv
         self._resident: List[bool] = [False] * n_inv
-        self.load_completed_event = None
         self.model_invocation_count = 0
         if name not in gpu_tensors:
             gpu_tensors[name] = [None] * PIPELINE_DEPTH
@@ -118,6 +117,11 @@ class MaybeOffloadedTensor:
     def _is_resident_now(self) -> bool:
         return (not self.is_offload_enabled) or self._resident[self.get_cur_model_invocation_key()]
 
+    def is_resident(self) -> bool:
+        """True when ``get_loaded_value()`` returns the stored tensor itself (offload off, or kept in HBM by the residency
+        policy) -- in-place consumers must then work on a copy; False when it returns a pipeline slot refilled from host."""
+        return self._is_resident_now()
+
     def get_loaded_value(self) -> Optional[torch.Tensor]:
         if self._is_resident_now():
             return self.gpu_tensor[self.get_cur_model_invocation_key()]
@@ -154,6 +158,3 @@ class MaybeOffloadedTensor:
         cur = torch.cuda.current_stream()
         cur.wait_stream(load_stream())
         cur.wait_stream(offload_stream())
-        if self.load_completed_event is not None:
-            self.load_completed_event.wait()
-            self.load_completed_event = None

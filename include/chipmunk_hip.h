@@ -40,6 +40,11 @@ int chipmunk_abi_version(void);
 /* Tuning knob: selects a kernel variant ("mm1_variant", "mm2_variant", "attn_variant", ...); 0 = shipped default.
  * Results are identical across variants; only speed differs.  Used by tools/kbench.py for A/B measurement. */
 int chipmunk_set_option(const char *name, int value);
+/* Seed of the random-key hash of chipmunk_topk_indices / _topk_delta_indices / _topk_mask (`random_amount` > 0).
+ * Every such launch draws a fresh set (per-launch salt = f(seed, launch counter), mixed on the device with the first
+ * element of each row); setting the seed restarts the sequence, so seed + launch order reproduce a run.  Replaces the
+ * reference's per-call cuRAND reseed (csrc/indexed_io/topk_indices.cu:46-49) and torch.randint (modules/attn.py:77). */
+int chipmunk_set_random_seed(uint64_t seed);
 
 /* ---------------------------------------------------------------- column-sparse attention
  * Replaces chipmunk::csp_attn (reference csrc/attn/csp_attn.cu:315-423; schema csrc/chipmunk.cpp:52).

@@ -276,8 +276,176 @@ def fp8_scales(ref):
     return out
 
 
+# ---------------------------------------------------------------------------------- reference Triton kernels on CPU
+def _patch_triton_interpreter_bf16():
+    """Triton 3.6's interpreter (TRITON_INTERPRET=1) keeps bf16 tensors as raw uint16 and neither `tl.dot` nor the binary
+    float ops decode them (a dot of bf16 ones returns 16256^2 * K), and its fp32 -> bf16 cast truncates where the GPU
+    rounds to nearest even.  This patches the TOOL (not the reference): bf16 operands are decoded to fp32, the op runs
+    in fp32, bf16 results are rounded to nearest even -- i.e. what the compiled kernel does on a GPU."""
+    import numpy as np
+    import triton.language as tl
+    import triton.runtime.interpreter as ti
+
+    def dec(u16):
+        return (np.ascontiguousarray(u16).astype(np.uint32) << 16).view(np.float32)
+
+    def enc(f32):
+        u = np.ascontiguousarray(f32, dtype=np.float32).view(np.uint32)
+        r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+        out = ((u + r) >> 16).astype(np.uint16)
+        nan = np.isnan(f32)
+        if np.any(nan):
+            out = np.where(nan, np.uint16(0x7FC0), out)
+        return out
+
+    B = ti.InterpreterBuilder
+    orig_cast, orig_f2f, orig_bin, orig_dot = B.cast_impl, B.create_fp_to_fp, B.binary_op, B.create_dot
+
+    def cast_impl(self, src, dst_type):
+        s, d = src.dtype.scalar, dst_type.scalar
+        if s == tl.bfloat16 and d == tl.float32:
+            return ti.TensorHandle(dec(src.data), d)
+        if s == tl.float32 and d == tl.bfloat16:
+            return ti.TensorHandle(enc(src.data), d)
+        return orig_cast(self, src, dst_type)
+
+    def create_fp_to_fp(self, src, dst_type, rounding_mode):
+        s, d = src.dtype.scalar, dst_type.scalar
+        if {s, d} == {tl.bfloat16, tl.float32}:
+            return cast_impl(self, src, dst_type)
+        return orig_f2f(self, src, dst_type, rounding_mode)
+
+    def binary_op(self, lhs, rhs, op):
+        if lhs.dtype.scalar == tl.bfloat16 and rhs.dtype.scalar == tl.bfloat16:
+            return ti.TensorHandle(enc(op(dec(lhs.data), dec(rhs.data))), tl.bfloat16)
+        return orig_bin(self, lhs, rhs, op)
+
+    def create_dot(self, a, b, d, input_precision, max_num_imprecise_acc):
+        if a.dtype.scalar == tl.bfloat16 or b.dtype.scalar == tl.bfloat16:
+            a = ti.TensorHandle(dec(a.data), tl.float32) if a.dtype.scalar == tl.bfloat16 else a
+            b = ti.TensorHandle(dec(b.data), tl.float32) if b.dtype.scalar == tl.bfloat16 else b
+        return orig_dot(self, a, b, d, input_precision, max_num_imprecise_acc)
+
+    B.cast_impl, B.create_fp_to_fp, B.binary_op, B.create_dot = cast_impl, create_fp_to_fp, binary_op, create_dot
+    for n in ("create_si_to_fp", "create_ui_to_fp", "create_fp_to_si", "create_fp_to_ui", "create_fp_ext", "create_fp_trunc"):
+        setattr(B, n, lambda self, src, dst_type: cast_impl(self, src, dst_type))
+
+
+def _load_reference_triton(fname):
+    """Execute a reference Triton source file with device='cuda' factory calls redirected to the CPU.  csp_mlp_mm2.py
+    launches its kernel once at import to grab the compiled function handle (`.function`, :131-138); under the
+    interpreter the launch returns None and the import stops THERE -- after the kernel and its wrapper are defined."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_triton_" + fname.replace(".py", ""), os.path.join(REF, "triton", fname))
+    mod = importlib.util.module_from_spec(spec)
+    real = {n: getattr(torch, n) for n in ("randn", "arange", "full", "empty")}
+
+    def cpuify(fn):
+        def w(*a, **k):
+            if k.get("device") == "cuda":
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return w
+    for n, f in real.items():
+        setattr(torch, n, cpuify(f))
+    import triton
+    real_autotune = triton.autotune
+    # the autotuner wants a GPU driver to time its candidate configs; num_stages / num_warps mean nothing to the interpreter
+    triton.autotune = lambda configs, key, **kw: (lambda fn: fn)
+    try:
+        spec.loader.exec_module(mod)
+    except AttributeError as e:
+        assert "function" in str(e), e
+    finally:
+        triton.autotune = real_autotune
+        for n, f in real.items():
+            setattr(torch, n, f)
+    return mod
+
+
+def kernel_pins(ref):
+    """Outputs of the REFERENCE's own kernels / helpers on seeded inputs -- the pins for ops that have no reference test:
+
+    * ``csp_mlp_mm2_kernel`` (triton/csp_mlp_mm2.py:26-129) and ``matmul_kernel_one_fp8`` (triton/csp_mlp_mm1.py:37-164)
+      executed by Triton's CPU interpreter (this script must be started with TRITON_INTERPRET=1);
+    * ``masktoinds`` (ops/voxel.py:161-180): counts and kept set of a mask -> indices conversion;
+    * ``SparseDiffAttn.random_and_topk`` (modules/attn.py:76-82) with the random part's RNG pinned.
+    Inputs are regenerated in the tests from the recorded seeds with the same helper (`_seeded`)."""
+    assert os.environ.get("TRITON_INTERPRET") == "1", "run as: TRITON_INTERPRET=1 python tests/golden/make_golden.py"
+    _patch_triton_interpreter_bf16()
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+
+    # ---- GEMM2: out[m,:] = bf16(sum_{c<count_g} a[m,c] * b[idx[g,c],:]) + out[m,:]
+    mm2 = _load_reference_triton("csp_mlp_mm2.py")
+    M, F, N2 = 384, 1024, 512
+    a, b, c0 = _seeded((M, F), 11, 0.5), _seeded((F, N2), 12, 0.1), _seeded((M, N2), 13)
+    inds = torch.stack([torch.randperm(F, generator=g) for _ in range(M // 128)]).to(torch.int32)
+    counts = torch.tensor([256, 768, 0], dtype=torch.int32)
+    c = c0.clone()
+    mm2.csp_mlp_mm2(a, b, inds, counts, c, 3)
+    out["mm2"] = {"shape": (M, F, N2), "seeds": (11, 12, 13), "scales": (0.5, 0.1, 1.0), "indices": inds, "counts": counts,
+                  "out": c, "num_sms": 3}
+    assert torch.equal(c[256:], c0[256:]), "a group with count 0 leaves its rows alone"
+
+    # ---- fp8 GEMM1: x = bf16(gelu((a8 . b8[idx]) * sa * sb + bias[idx])); c = x - cache[idx, m]; cache[idx, m] = x
+    mm1 = _load_reference_triton("csp_mlp_mm1.py")
+    M, K, F = 256, 384, 1024
+    a8 = _seeded((M, K), 21, 0.8).to(torch.float8_e4m3fn)
+    b8 = _seeded((F, K), 22, 0.6).to(torch.float8_e4m3fn)
+    bias, cache0 = _seeded((F,), 23, 0.2), _seeded((F, M), 24, 0.5)
+    inds = torch.stack([torch.randperm(F, generator=g) for _ in range(M // 128)]).to(torch.int32)
+    counts = torch.tensor([512, 256], dtype=torch.int32)
+    sa, sb = torch.tensor([0.0625], dtype=torch.float32), torch.tensor([0.03125], dtype=torch.float32)
+    cache, packed = cache0.clone(), torch.zeros(M, F, dtype=torch.bfloat16)
+    mm1.csp_mlp_mm1(a8, b8, bias, inds, counts, cache, packed, sa, sb)
+    out["mm1_fp8"] = {"shape": (M, K, F), "seeds": (21, 22, 23, 24), "scales": (0.8, 0.6, 0.2, 0.5), "indices": inds,
+                      "counts": counts, "scale_a": sa, "scale_b": sb, "packed": packed, "cache": cache}
+
+    # ---- masktoinds: counts (rounded up to `multiple`) and the kept set (the first popcount entries of each row)
+    mask = torch.rand(2, 3, 5, 700, generator=g) < 0.23
+    mask[0, 0, 1] = False
+    mask[1, 2, 4] = True
+    mi, mc = ref["voxel"].masktoinds(mask, multiple=128)
+    pop = mask.sum(-1)
+    kept = torch.full(mask.shape, -1, dtype=torch.int32)
+    for idx in torch.cartesian_prod(*[torch.arange(n) for n in mask.shape[:-1]]):
+        i = tuple(idx.tolist())
+        kept[i][: pop[i]] = mi[i][: pop[i]].sort().values
+    out["masktoinds"] = {"mask": mask, "counts": mc, "kept_sorted": kept, "popcount": pop.to(torch.int32)}
+
+    # ---- random_and_topk with the random draw pinned to "nothing" and to a fixed pattern
+    cfg = ref["cfg"].GLOBAL_CONFIG
+    cfg["offloading"]["global_disable_offloading"] = True
+    vid, txt, H = (8, 12, 16), 40, 2
+    N = vid[0] * vid[1] * vid[2] + txt
+    cfg["attn"].update(dict(top_keys=0.05, random_keys=0.0, local_voxels=1, local_1d_window=0))
+    layer = ref["mattn"].SparseDiffAttn(0, ref["lc"].LayerCounter(1, 1))
+    torch.manual_seed(5)
+    layer.initialize_static_mask(vid, txt, H, torch.device("cpu"))
+    G = (N + 191) // 192
+    # tie-free rows: make every row a permutation of distinct bf16 values
+    base = (torch.arange(N, dtype=torch.int32) + 0x3C00).to(torch.int16).view(torch.bfloat16)   # N consecutive bf16 values
+    assert base.unique().numel() == N
+    cs = torch.stack([base[torch.randperm(N, generator=g)] for _ in range(H * G)]).view(1, H, G, N)
+    real_randint = torch.randint
+    res = {}
+    for tag, fake in (("norand", lambda lo, hi, shape, **k: torch.ones(shape, dtype=k.get("dtype", torch.int64))),):
+        torch.randint = fake
+        try:
+            res[tag] = ref["bitpack"].bitpack(layer.random_and_topk(cs, 128))[0]
+        finally:
+            torch.randint = real_randint
+    sm, sg = ref["mattn"].singleton_static_mask, ref["mattn"].singleton_video_query_groups
+    out["random_and_topk"] = {"cs": cs, "k": 128, "static_mask_packed": ref["bitpack"].bitpack(sm)[0], "static_shape": tuple(sm.shape),
+                              "groups": sg.clone(), "mask_norand_packed": res["norand"], "mask_shape": (1, H, G, N)}
+    return out
+
+
 def main():
     ref = import_reference()
+    if os.environ.get("TRITON_INTERPRET") == "1":
+        torch.save(kernel_pins(ref), os.path.join(HERE, "kernel_pins.pt"))
     torch.save(layer_counter_traces(ref), os.path.join(HERE, "layer_counter.pt"))
     torch.save(config_merges(ref), os.path.join(HERE, "config_merge.pt"))
     torch.save(patch_voxel_bitpack(ref), os.path.join(HERE, "layout_ops.pt"))
