@@ -253,6 +253,58 @@ def module_runs(ref):
     return out
 
 
+def structured_module_runs(ref):
+    """The reference's SparseDiffAttn on inputs with planted structure (tests/helpers.py: structured_qkv), FLUX style
+    and HunyuanVideo style, with the 1 % random keys switched off (torch.randint pinned): per-step output digests for
+    the GPU module parity test (tests/test_gpu_module_parity.py), which runs this build's modules on HIP kernels."""
+    import cpu_ops
+    from helpers import structured_qkv
+    cpu_ops.register()
+    cfg = ref["cfg"].GLOBAL_CONFIG
+    cfg["offloading"]["global_disable_offloading"] = True
+    cfg["steps"] = 50
+    out = {}
+    real_randint = torch.randint
+    torch.randint = lambda lo, hi, shape, **k: torch.ones(shape, dtype=k.get("dtype", torch.int64))
+    try:
+        # FLUX style
+        cfg["attn"].update(dict(top_keys=0.165, full_step_every=10, full_step_schedule=None, first_n_dense_layers=1,
+                                recompute_mask=False, should_compress_indices=False, counts_multiple_of=112,
+                                pad_qkv_before_kernel=False, random_keys=0.0, local_voxels=0))
+        H, N, n_hot = 2, 1360, 130
+        counter = ref["lc"].LayerCounter(2, 1)
+        layers = [ref["mattn"].SparseDiffAttn(i, counter) for i in range(2)]
+        outs = []
+        for step in range(12):
+            for li, layer in enumerate(layers):
+                q, k, v, _ = structured_qkv(H, N, n_hot, step, li)
+                outs.append(digest(layer(q, k, v)))
+        out["flux"] = {"H": H, "N": N, "n_hot": n_hot, "steps": 12, "outs": outs,
+                       "indices": layers[1].storage.get_indices()[..., :224].sort(-1).values.clone(),
+                       "counts": layers[1].storage.get_counts().clone()}
+        # HunyuanVideo style
+        cfg["attn"].update(dict(top_keys=0.05, random_keys=0.0, local_voxels=0, first_n_dense_layers=1,
+                                recompute_mask=True, should_compress_indices=True, counts_multiple_of=128,
+                                pad_qkv_before_kernel=True, full_step_schedule={0, 1, 4}))
+        vid, txt, n_hot = (8, 12, 16), 40, 80
+        N = vid[0] * vid[1] * vid[2] + txt
+        counter = ref["lc"].LayerCounter(2, 1)
+        layers = [ref["mattn"].SparseDiffAttn(i, counter) for i in range(2)]
+        torch.manual_seed(123)
+        layers[0].initialize_static_mask(vid, txt, H, torch.device("cpu"))
+        outs = []
+        for step in range(7):
+            for li, layer in enumerate(layers):
+                q, k, v, _ = structured_qkv(H, N, n_hot, step, li)
+                outs.append(digest(layer(q, k, v)))
+        out["hunyuan"] = {"H": H, "vid": vid, "txt": txt, "n_hot": n_hot, "steps": 7, "outs": outs,
+                          "packed_mask": layers[1].storage.get_indices().clone(), "mask_shape": tuple(layers[1].mask_shape[0])}
+        cfg["attn"]["full_step_schedule"] = None
+    finally:
+        torch.randint = real_randint
+    return out
+
+
 def fp8_scales(ref):
     """F8Linear scale arithmetic of the reference (modules/mlp_fp8.py:169-221) on fixed tensors --
     weight quantisation, and the input scale over 14 calls (12 calibration trials, the freezing call, one frozen)."""
@@ -450,6 +502,7 @@ def main():
     torch.save(config_merges(ref), os.path.join(HERE, "config_merge.pt"))
     torch.save(patch_voxel_bitpack(ref), os.path.join(HERE, "layout_ops.pt"))
     torch.save(module_runs(ref), os.path.join(HERE, "module_runs.pt"))
+    torch.save(structured_module_runs(ref), os.path.join(HERE, "module_runs_structured.pt"))
     torch.save(fp8_scales(ref), os.path.join(HERE, "fp8_scales.pt"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
