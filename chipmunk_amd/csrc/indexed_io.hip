@@ -278,7 +278,7 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
         else return b;
     };
 
-    const uint32_t salt = p.salt ^ (__float_as_uint(load_as_float<T>(x, 0)) * 0x27D4EB2Fu);
+    const uint32_t salt = p.salt ^ (__float_as_uint(value(0)) * 0x27D4EB2Fu);  // the fused (delta) form sees what the unfused op sees
     if (p.quantile == 0.f) {  // keep everything (topk_indices.cu:51-59)
         if constexpr (DELTA)
             for (int c = tid; c < cols; c += 1024) xc[c] = x[c];

@@ -118,15 +118,22 @@ def test_topk_delta_indices_equals_unfused_sequence(dev, sparsity, multiple_of, 
     i1 = torch.full((B, R, C), -9, dtype=torch.int32, device=dev)
     c1 = torch.zeros(B, R, dtype=torch.int32, device=dev)
     cache1 = cache0.clone()
+    import chipmunk_amd.ops as cm_ops
+    cm_ops.manual_seed(99)      # random keys: every launch draws a fresh set; same seed + same launch order = same set
     torch.ops.chipmunk.topk_indices(mdiff, i1, c1, sparsity, multiple_of, rk)
     torch.ops.chipmunk.copy_indices(b, cache1, i1, c1)
     # fused
     i2 = torch.full((B, R, C), -9, dtype=torch.int32, device=dev)
     c2 = torch.zeros(B, R, dtype=torch.int32, device=dev)
     cache2 = cache0.clone()
+    cm_ops.manual_seed(99)
     torch.ops.chipmunk.topk_delta_indices(b, cache2, i2, c2, sparsity, multiple_of, rk)
     assert torch.equal(c1, c2) and torch.equal(i1, i2)
     assert torch.equal(cache1.view(torch.int16), cache2.view(torch.int16))
+    if rk > 0.0:    # a second launch draws other random columns (the random keys exist to refresh stale cache columns)
+        i3, c3 = torch.full_like(i2, -9), torch.zeros_like(c2)
+        torch.ops.chipmunk.topk_indices(mdiff, i3, c3, sparsity, multiple_of, rk)
+        assert not torch.equal(i3, i1)
     if rk == 0.0:   # and against the oracle on the eager |delta|
         ri = torch.full((B, R, C), -9, dtype=torch.int32)
         rc = torch.zeros(B, R, dtype=torch.int32)

@@ -108,9 +108,10 @@ def _run_hunyuan(gold, dev, exact):
     assert torch.equal(mask[:, :, -1], ref_mask[:, :, -1])
     if exact:
         assert torch.equal(mask, ref_mask)
-    else:   # same popcount per row up to the ~1 % hash-random extra columns of the fused top-k mask kernel
+    else:   # same popcount per row up to the ~1 % hash-random extra columns of the fused top-k mask kernel and a few
+        #         filler columns that coincide (or not) with static-mask columns
         d = (mask.sum(-1) - ref_mask.sum(-1)).float()
-        assert d.min() >= 0 and d.max() <= 0.03 * N
+        assert d.min() >= -8 and d.max() <= 0.03 * N
 
 
 # ------------------------------------------------------------------------------------------------ CPU: mirror, bit-exact

@@ -168,8 +168,10 @@ def test_hip_mask_to_indices_matches_reference_masktoinds(pins, dev):
     inds, counts = torch.ops.chipmunk.mask_to_indices(mask, 128, 192)
     assert torch.equal(counts.cpu(), p["counts"])
     sinds, scounts = torch.ops.chipmunk.mask_to_sorted_indices(mask, list(mask.shape), 128, 192)
-    packed = torch.ops.chipmunk.bitpack(mask)
-    pinds, pcounts = torch.ops.chipmunk.packed_mask_to_indices(packed, list(mask.shape), 128, 192)
+    # the bit-packed form needs whole bytes per row (n % 8 == 0): pad the columns with False
+    padded = torch.nn.functional.pad(mask, (0, (-mask.shape[-1]) % 8))
+    packed = torch.ops.chipmunk.bitpack(padded)
+    pinds, pcounts = torch.ops.chipmunk.packed_mask_to_indices(packed, list(padded.shape), 128, 192)
     assert torch.equal(scounts.cpu(), p["counts"]) and torch.equal(pcounts.cpu(), p["counts"])
     inds, sinds, pinds = inds.cpu(), sinds.cpu(), pinds.cpu()
     for idx in torch.cartesian_prod(*[torch.arange(n) for n in p["mask"].shape[:-1]]):
