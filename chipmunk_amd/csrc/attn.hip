@@ -49,7 +49,9 @@ struct AttnParams {
     int split_full, nsplit;
     float *ws;
     int32_t *tickets;
-    const int32_t *order;  // optional work order: block i processes (head, group) item order[i]
+    // optional work plan for ragged key counts (attn_plan_kernel): block i processes item plan[2i] (< 0: nothing), slice
+    // (plan[2i+1] & 0xffff) of (plan[2i+1] >> 16) slices over the item's key tiles; slices of one item are adjacent
+    const int32_t *plan;
     int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
@@ -91,15 +93,22 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int li = lane & 15, lg = lane >> 4;
 
     int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    int sp = 0, nsp = 1, tail_item = 0;
-    if (!CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
+    // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
+    int sp = 0, nsp = 1, slot0 = 0, tix = 0, wid = wid0;
+    if (!CSONLY && p.plan) {
+        wid = p.plan[2 * wid0];
+        if (wid < 0) return;
+        const int meta = p.plan[2 * wid0 + 1];
+        sp = meta & 0xffff, nsp = meta >> 16;
+        slot0 = tix = wid0 - sp;
+    } else if (!CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
         const int k = wid0 - p.split_full;
-        tail_item = k / p.nsplit;
-        sp = k - tail_item * p.nsplit;
+        tix = k / p.nsplit;
+        sp = k - tix * p.nsplit;
         nsp = p.nsplit;
-        wid0 = p.split_full + tail_item;
+        slot0 = tix * p.nsplit;
+        wid = p.split_full + tix;
     }
-    const int wid = p.order ? p.order[wid0] : wid0;
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
 
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
     const int valid = count < p.Nk ? count : p.Nk;
     const int ntiles = (valid + KVT - 1) / KVT;
-    if (!CSONLY && nsp > 1) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
+    if (!CSONLY && nsp > 1 && !p.plan) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
         const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
         nsp = nsp < cap ? nsp : cap;
         if (sp >= nsp) return;
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         //      wrong elements at HunyuanVideo scale in one build and none in the next: loads the compiler cannot see
         //      are not worth ~1 % of a launch.)
         int *ticket_s = (int *)cs_acc;
-        f32x4 *mine = (f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + sp) * (26 * 256) + tid;
+        f32x4 *mine = (f32x4 *)p.ws + (int64_t)(slot0 + sp) * (26 * 256) + tid;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
@@ -414,12 +423,12 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait (see guide)
-            *ticket_s = __hip_atomic_fetch_add(p.tickets + tail_item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *ticket_s = __hip_atomic_fetch_add(p.tickets + tix, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (*ticket_s != nsp - 1) return;
         if (tid == 0) {
-            __hip_atomic_store(p.tickets + tail_item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            __hip_atomic_store(p.tickets + tix, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             for (int db = 0; db < 8; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         for (int s2 = 0; s2 < nsp; ++s2) {
-            const f32x4 *oth = (const f32x4 *)p.ws + ((int64_t)tail_item * p.nsplit + s2) * (26 * 256) + tid;
+            const f32x4 *oth = (const f32x4 *)p.ws + (int64_t)(slot0 + s2) * (26 * 256) + tid;
             const f32x4 ms = oth[24 * 256], ls = oth[25 * 256];
 #pragma unroll
             for (int qb = 0; qb < 3; ++qb) {
@@ -491,28 +500,66 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 }
 
-// Longest-first work order for ragged key counts (HunyuanVideo: the text / tail query groups keep ALL 119k keys, 13x
-// the work of a normal group; dispatched last they leave a ~10 ms tail with two workgroups running).  Items whose
-// count exceeds twice the average go first; everything else keeps the natural (head, group) order, which is what keeps
-// one head's K/V hot in L2 / Infinity Cache.  One 1024-thread workgroup, a few microseconds.
-__global__ __launch_bounds__(1024) void attn_order_kernel(const int32_t *counts, int32_t *order, int n) {
+// Work plan for ragged key counts.  HunyuanVideo's text / tail query groups keep ALL 119k keys (13x a normal group); a
+// head-parallel rank launches only 3 heads (1 863 items on 512 slots), so one such item -- 6 ms on one workgroup -- would
+// be the whole launch.  One 1024-thread workgroup (a few microseconds) builds the plan on the device (the host never
+// reads the counts):
+//   * L = sum(counts) / slots is a slot's share at perfect balance; items above 1.5 T, T = max(L/4, 4096 keys), are cut
+//     into ceil(count / T) slices (<= 64) over their key tiles -- each slice is a workgroup, partial (o, m, l) go through
+//     scratch and the last arriver merges (same hand-off as the dense key-split tail);
+//   * sliced items go FIRST (longest-first), everything else keeps the natural (head, group) order, which keeps one
+//     head's K/V hot in L2 / Infinity Cache;
+//   * T doubles until the slices fit `max_slices` (the scratch the host reserved); unused plan entries are -1.
+__global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *counts, int32_t *plan, int n, int Nk, int slots,
+                                                        int max_slices, int cap) {
     __shared__ unsigned long long total;
-    __shared__ int n_heavy, wave_tot[16], base_s;
+    __shared__ int n_slices, wave_tot[16], base_s, T_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) total = 0, n_heavy = 0, base_s = 0;
+    auto cnt = [&](int i) {
+        const int c = counts[i];
+        return c < 0 ? 0 : (c < Nk ? c : Nk);
+    };
+    if (tid == 0) total = 0, n_slices = 0, base_s = 0;
     __syncthreads();
     unsigned long long mine = 0;
-    for (int i = tid; i < n; i += 1024) mine += (unsigned)counts[i];
+    for (int i = tid; i < n; i += 1024) mine += (unsigned)cnt(i);
     atomicAdd(&total, mine);
     __syncthreads();
-    const long long thr = 2 * (long long)(total / (unsigned long long)n);
-    for (int i = tid; i < n; i += 1024)
-        if (counts[i] > thr) order[atomicAdd(&n_heavy, 1)] = i;
+    long long T = (long long)(total / (unsigned long long)slots) / 4;
+    T = T < 4096 ? 4096 : T;
+    T = (T + KVT - 1) / KVT * KVT;
+    auto slices_of = [&](int c, long long t) {
+        if (2 * (long long)c <= 3 * t) return 1;
+        const long long k = (c + t - 1) / t;
+        return (int)(k > 64 ? 64 : k);
+    };
+    for (int round = 0; round < 24; ++round) {  // T doubles until the sliced items fit the reserved scratch
+        int need = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const int k = slices_of(cnt(i), T);
+            need += k > 1 ? k : 0;
+        }
+        if (tid == 0) T_s = 0;
+        __syncthreads();
+        atomicAdd(&T_s, need);
+        __syncthreads();
+        const int tot = T_s;
+        __syncthreads();
+        if (tot <= max_slices) break;
+        T *= 2;
+    }
+    for (int i = tid; i < n; i += 1024) {
+        const int k = slices_of(cnt(i), T);
+        if (k > 1) {
+            const int base = atomicAdd(&n_slices, k);
+            for (int s2 = 0; s2 < k; ++s2) plan[2 * (base + s2)] = i, plan[2 * (base + s2) + 1] = s2 | (k << 16);
+        }
+    }
     __syncthreads();
-    const int nh = n_heavy;
-    for (int i0 = 0; i0 < n; i0 += 1024) {  // ordered compaction of the light items
+    const int nh = n_slices;
+    for (int i0 = 0; i0 < n; i0 += 1024) {  // ordered compaction of the unsliced items
         const int i = i0 + tid;
-        const bool light = i < n && counts[i] <= thr;
+        const bool light = i < n && slices_of(cnt(i), T) == 1;
         const unsigned long long bal = __ballot(light);
         if (lane == 0) wave_tot[w] = __popcll(bal);
         __syncthreads();
@@ -521,11 +568,15 @@ __global__ __launch_bounds__(1024) void attn_order_kernel(const int32_t *counts,
             off += j < w ? wave_tot[j] : 0;
             tot += wave_tot[j];
         }
-        if (light) order[nh + off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        if (light) {
+            const int e = nh + off + __popcll(bal & ((1ull << lane) - 1ull));
+            plan[2 * e] = i, plan[2 * e + 1] = 1 << 16;
+        }
         __syncthreads();
         if (tid == 0) base_s += tot;
         __syncthreads();
     }
+    for (int e = nh + base_s + tid; e < cap; e += 1024) plan[2 * e] = -1, plan[2 * e + 1] = 1 << 16;
 }
 
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
@@ -549,23 +600,32 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     pp.xcd_chunks = xo == 2 ? (GATHER ? 1 : 0) : xo;
     // scratch layout: [tickets: TICKET_BYTES, always left at zero][work order | split partials]
     constexpr size_t TICKET_BYTES = 64 << 10;
-    if (GATHER && nblocks >= 2048 && !chipmunk_get_option("attn_no_order")) {
-        unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, TICKET_BYTES + (size_t)nblocks * sizeof(int32_t));
-        if (sc) {
-            int32_t *order = (int32_t *)(sc + TICKET_BYTES);
-            hipLaunchKernelGGL(attn_order_kernel, dim3(1), dim3(1024), 0, stream, p.counts, order, (int)nblocks);
-            pp.order = order;
+    int64_t grid = nblocks;
+    if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768) && !chipmunk_get_option("attn_no_order")) {
+        const int slots = 2 * device_cu_count();
+        const int max_slices = 3 * slots;                         // 1536 x 104 KB = 160 MB of partials at most
+        const int64_t cap = nblocks + max_slices;                 // plan entries == workgroups launched
+        const size_t plan_bytes = (size_t)cap * 2 * sizeof(int32_t);
+        const size_t ws_off = (TICKET_BYTES + plan_bytes + 255) & ~(size_t)255;
+        unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, ws_off + (size_t)max_slices * 26 * 256 * sizeof(f32x4));
+        if (sc && (size_t)max_slices * sizeof(int32_t) <= TICKET_BYTES) {
+            int32_t *plan = (int32_t *)(sc + TICKET_BYTES);
+            hipLaunchKernelGGL(attn_plan_kernel, dim3(1), dim3(1024), 0, stream, p.counts, plan, (int)nblocks, p.Nk, slots,
+                               max_slices, (int)cap);
+            pp.plan = plan;
+            pp.tickets = (int32_t *)sc;
+            pp.ws = (float *)(sc + ws_off);
             pp.xcd_chunks = 0;
+            grid = cap;
         }
     }
     // Key-split tail.  Workgroups are dispatched in block order as the 2-per-CU slots free up; with near-equal items
     // the last (nblocks mod slots) of them run alone for a full item time (FLUX: 24 heads x 23 groups = 552 items on
     // 512 slots -> half of the launch is a 8 %-full second round).  Those items (or all of them when the whole grid
     // is under half the machine) are split over their key tiles into up to 8 workgroups each.
-    int64_t grid = nblocks;
     // Dense launches only by default: a gathered FLUX item is ~45 us of which ~11 us are fixed costs every slice pays
     // again, and the split measured 94 -> 105 us there (option attn_split_gather forces it, for the tests).
-    if (!CSONLY && !pp.order && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
+    if (!CSONLY && !pp.plan && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
         (!GATHER || chipmunk_get_option("attn_split_gather"))) {
         const int64_t slots = 2 * (int64_t)device_cu_count();
         const int64_t rem = nblocks <= slots / 2 ? nblocks : nblocks % slots;

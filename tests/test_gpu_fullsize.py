@@ -185,3 +185,55 @@ def test_key_split_tail_matches_unsplit_at_scale():
         # launch does, so about half of THEIR elements move by one last bit; everything else is untouched
         assert (d > 0).float().mean().item() < 0.06
         assert d.mean().item() < 2.0 ** -11 * o_ref.float().abs().mean().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [1, 3])
+def test_sliced_heavy_items_match_unsliced_and_oracle(H):
+    """Ragged key counts with few heads (the head-parallel C4 case: 3 heads per rank): items far above a slot's share are
+    cut into slices over their key tiles by the device-built work plan (attn_plan_kernel) and merged by the last arriver.
+    Compared with the same launch without the plan (option attn_no_order) and, on the heavy groups, with the oracle; the
+    in-place / out-of-place accumulate forms go through the same plan."""
+    from chipmunk_amd import _native
+    dev = torch.device("cuda:0")
+    N = 33000                                   # >= 32768 keys: the plan is on; 172 query groups, ragged last one
+    G = (N + 191) // 192
+    g = torch.Generator().manual_seed(5 + H)
+    q, k, v = [randn_bf16(1, H, N, 128, seed=40 + s + H) for s in range(3)]
+    inds = torch.empty(1, H, G, G * 192, dtype=torch.int32)
+    counts = torch.full((1, H, G), 512, dtype=torch.int32)
+    for h in range(H):
+        for gi in range(G):
+            inds[0, h, gi, :N] = torch.randperm(N, generator=g).to(torch.int32)
+            inds[0, h, gi, N:] = 0
+    counts[0, :, 5] = N                          # a text-like group that keeps every key
+    counts[0, :, G - 1] = 20000                  # the ragged tail group keeps most
+    counts[0, 0, 7] = 0                          # and an empty one
+    counts[0, H - 1, 9] = 33                     # not a multiple of the tile
+    qd, kd, vd, indd, cntd = [t.to(dev) for t in (q, k, v, inds, counts)]
+    for rep in range(2):
+        o = torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd)
+        _native.set_option("attn_no_order", 1)
+        try:
+            o_plain = torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd)
+        finally:
+            _native.set_option("attn_no_order", 0)
+        d = (o.float() - o_plain.float()).abs()
+        assert d.max().item() <= 2.0 ** -7 * max(1e-3, o_plain.float().abs().max().item()), d.max().item()
+        light = torch.ones(G, dtype=torch.bool)
+        light[[5, G - 1]] = False
+        rows = light.repeat_interleave(192)[:N].to(dev)
+        assert torch.equal(o[:, :, rows], o_plain[:, :, rows]), "unsliced items are computed exactly as before"
+    # heavy groups against the oracle (only those: the oracle is a scalar restatement)
+    for gi in (5, G - 1, 7, 9):
+        r0, r1 = gi * 192, min(N, gi * 192 + 192)
+        o_ref = oracle.csp_128_attn(q[:, :, r0:r1].contiguous(), k, v, inds[:, :, gi:gi + 1, :N].contiguous(), counts[:, :, gi:gi + 1].contiguous())
+        assert_close_bf16(o[:, :, r0:r1], o_ref, what=f"group {gi} vs oracle")
+    # accumulate forms
+    base = randn_bf16(1, H, N, 128, seed=77)
+    out = torch.ops.chipmunk.csp_attn_out(qd, kd, vd, base.to(dev), indd, cntd, -1)
+    want = (base.float() - o.float().cpu().to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert_close_bf16(out, want, atol=1e-2, rtol=1e-2, what="csp_attn_out with sliced items")
+    inpl = base.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, inpl, indd, cntd, -1)
+    assert torch.equal(inpl, out), "in-place and out-of-place accumulate agree bit for bit"
