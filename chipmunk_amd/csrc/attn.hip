@@ -28,7 +28,8 @@ constexpr int KRING = 8;  // key ring slots (keys travel NST-1+3 tiles ahead of 
 constexpr int HD = 128;   // head dim (reference: "Head dimension must be 128", csp_attn.cu:381-383)
 constexpr int TILE_BYTES = KVT * HD * 2;  // 8 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;  // csp_128_attn.cu:307
-constexpr int KEY_RING_OFF = 2 * NST * TILE_BYTES;
+constexpr int NSTV = NST + 1;  // V ring: one slot deeper, tile t-1's V is read during iteration t (PV runs one tile behind QK^T)
+constexpr int KEY_RING_OFF = (NST + NSTV) * TILE_BYTES;
 constexpr int CS_OFF = KEY_RING_OFF + KRING * 256;
 constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * 2 * 4 * KVT * 4;  // column-sum partials [2 iterations][2 tiles][4 waves][KVT]
 
@@ -60,6 +61,52 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifdef ATTN_PROF
+// Cycle anatomy of the main loop (tools/attn_prof.py builds a separate library with -DATTN_PROF): per wave of
+// workgroup 0, s_memtime at the segment boundaries of every tile, summed per segment.  Not part of the product build.
+__device__ unsigned long long g_attn_prof[8 * 8];
+#define PROF_DECL unsigned long long pt_, pacc_[7] = {0, 0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == (gridDim.x / 2)
+#define PROF_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROF_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define PROF_END(w, ntiles) do { if (prof_on_ && lane == 0) { for (int i_ = 0; i_ < 7; ++i_) g_attn_prof[(w) * 8 + i_] = pacc_[i_]; g_attn_prof[(w) * 8 + 7] = (ntiles); } } while (0)
+extern "C" int chipmunk_attn_prof_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_prof), sizeof(g_attn_prof)) == hipSuccess ? 0 : 2;
+}
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_MARK(i)
+#define PROF_END(w, ntiles)
+#endif
+
+// Pin a value to this point of the program: the optimiser may neither sink its computation below nor hoist its uses above
+// (the IR passes move pure arithmetic across sched_barrier freely; a hand-placed slice has to materialise where it stands).
+template <typename T>
+__device__ __forceinline__ void pin(T &x) {
+    asm volatile("" : "+v"(x));
+}
+
+// three-input maximum as ONE instruction (nested fmaxf on MFMA outputs makes hipcc insert canonicalising v_max first)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max over the four 16-lane rows of a wave (common.h: max_across_rows) without the canonicalising v_max pairs
+__device__ __forceinline__ float max_rows(float x) {
+    float a = x, b = x;
+    lane_swap32(a, b);
+    float c = max2(a, b), d = c;
+    lane_swap16(c, d);
+    return max2(c, d);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -79,9 +126,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KEYOFF = (CSONLY ? 1 : 2) * NST * TILE_BYTES;  // the column-sum pass has no V ring
+    constexpr int KEYOFF = (CSONLY ? NST : NST + NSTV) * TILE_BYTES;  // the column-sum pass has no V ring
     unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
-    unsigned char *Vl = smem + NST * TILE_BYTES;   // [NST][TILE_BYTES]
+    unsigned char *Vl = smem + NST * TILE_BYTES;   // [NSTV][TILE_BYTES]
     int *key_ring = (int *)(smem + KEYOFF);        // [KRING][64]
     // [2][2][4][KVT]: per-wave column-sum partials of the CSONLY pass (iteration parity, tile parity, wave), summed in
     // wave order (the reference reduces with shared-memory atomics and is order-dependent in the last bits; this is
@@ -181,9 +228,10 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
             const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
             blds16(krsrc, koff, 0, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
-            if constexpr (!CSONLY) blds16(vrsrc, voff, 0, Vl + slot * TILE_BYTES + (w * 2 + i) * 1024);
+            if constexpr (!CSONLY) blds16(vrsrc, voff, 0, Vl + (T % NSTV) * TILE_BYTES + (w * 2 + i) * 1024);
         }
     };
+
 
     f32x4 o[3][8];
 #pragma unroll
@@ -278,37 +326,44 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         return;
     }
 
-    for (int t = tbeg; t < tend; ++t) {
-        const int slot = t % NST;
-        // tile t has landed once at most the NST-2 younger groups (4 DMAs each, +1 key DMA on wave 0) are in flight
-        if (t + NST - 1 <= tend) {
-            constexpr int L = 4;  // DMA instructions per wave per tile
-            if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
-            else wait_vmcnt<(NST - 2) * L>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        if (t + NST - 1 < tend && (p.probe & 3) != 1) {
-            issue_data(t + NST - 1);
-            issue_keys(t + 2 * (NST - 1));
-        }
-        if ((p.probe & 3) == 2) continue;
-        const unsigned char *Kb = Kl + slot * TILE_BYTES;
-        const unsigned char *Vb = Vl + slot * TILE_BYTES;
-
-        // ---- S^T = K . Q^T : s[qb][kt][r] = score(kv = kt*16 + lg*4 + r, q = qb*16 + li)
+    PROF_DECL;
+    PROF_START();
+    {
+        // ---- pipelined loop: PV runs ONE TILE BEHIND QK^T.  Iteration t: S(t) = K(t).Q^T, then ONE scheduling region holding
+        // the 24 MFMAs of O += V(t-1).P(t-1) and the softmax of S(t): the softmax VALU/exp instructions issue in the
+        // shadow of MFMAs that do not depend on them (a lone wave spends ~2100 of its ~2900 cycles per tile outside the
+        // matrix pipe, most of it exposed VALU / LDS latency; tools/attn_prof.py).  Costs 12 registers (P of two tiles)
+        // and one more V slot in LDS.
+        // The reference point m of the exponentials lags the true running maximum by at most MAX_LAG (in exp2 units): p <= 2^4,
+        // the relative precision of the bf16 P and of the fp32 sums is unchanged, and the O / l rescale (72 VALU issues) runs
+        // only when some query column of the wave outgrows the lag -- VALU issue slots, not MFMA time, bound this loop.
+        constexpr float MAX_LAG = 4.0f;
+        bf16x8 pq[3];   // P^T of the tile whose PV is pending
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) pq[qb] = (bf16x8){};
         f32x4 s[3][2];
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // K fragments run through a 3-deep register ring (two reads in flight ahead of the MFMAs that consume them;
-        // left alone hipcc emits read -> lgkmcnt(0) -> 3 MFMA per fragment and exposes the LDS latency every time)
-        {
-            auto load_k = [&](int idx) {
-                const int kt = idx >> 2, ks = idx & 3;
-                const int pc = (ks * 4 + lg) ^ li;  // swizzled 16-byte chunk; row & 15 == li
+        float alpha[3] = {1.f, 1.f, 1.f};
+        auto tile_sync = [&](int t) {   // tile t has landed for everybody; the DMA of tile t+3 goes out
+            if (t + NST - 1 <= tend) {
+                constexpr int L = 4;
+                if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
+                else wait_vmcnt<(NST - 2) * L>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            PROF_MARK(0);
+            if (t + NST - 1 < tend) {
+                issue_data(t + NST - 1);
+                issue_keys(t + 2 * (NST - 1));
+            }
+            PROF_MARK(1);
+        };
+        auto qk_tile = [&](int t) {     // S^T(t) = K(t) . Q^T, dead keys of a ragged last tile masked
+            const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
+            auto load_k = [&](int i) {
+                const int kt = i >> 2, ks = i & 3;
+                const int pc = (ks * 4 + lg) ^ li;
                 return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
             };
             constexpr int FR = 3;
@@ -316,91 +371,174 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 #pragma unroll
             for (int i = 0; i < FR - 1; ++i) kr[i] = load_k(i);
 #pragma unroll
-            for (int idx = 0; idx < 8; ++idx) {
-                if (idx + FR - 1 < 8) kr[(idx + FR - 1) % FR] = load_k(idx + FR - 1);
+            for (int i = 0; i < 8; ++i) {
+                if (i + FR - 1 < 8) kr[(i + FR - 1) % FR] = load_k(i + FR - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const int kt = idx >> 2, ks = idx & 3;
+                const int kt = i >> 2, ks = i & 3;
+                // the first k step starts from the inline constant 0 (an explicit zero fill costs 24 VALU issues per tile)
 #pragma unroll
                 for (int qb = 0; qb < 3; ++qb)
-                    s[qb][kt] = mfma16(kr[idx % FR], qf[qb][ks], s[qb][kt]);
+                    s[qb][kt] = mfma16(kr[i % FR], qf[qb][ks], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-
-        if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
+            if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
 #pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
-                }
-        }
-
-        // the first two V^T fragments are fetched BEFORE the softmax so their LDS latency hides behind its VALU work
-        auto load_v = [&](int db) {
-            const int row_a = lg * 4 + (li >> 2);
-            const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
-            const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
-            const s16x4 lo = lds_read_tr16_b64(va);
-            const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
-            return __builtin_bit_cast(
-                bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-        };
-        constexpr int VR = 3;
-        bf16x8 vr[VR];
-#pragma unroll
-        for (int i = 0; i < VR - 1; ++i) vr[i] = load_v(i);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- online softmax (exp2 domain, running max of the raw scores: csp_128_attn.cu:308-324)
-        bf16x8 pb[3];
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
-            float mx = s[qb][0][0];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
-            mx = max_across_rows(mx);
-            const float m_new = fmaxf(m[qb], mx);  // finite: every tile holds at least one live key
-            const float msc = m_new * SCALE_LOG2E;
-            const float alpha = __builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E - msc);
-            m[qb] = m_new;
-            float psum = 0.f;
-            float pv[2][4];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
-                    psum += pv[kt][r];
-                }
-            lsum[qb] = lsum[qb] * alpha + psum;
-            if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                for (int db = 0; db < 8; ++db) o[qb][db] *= alpha;
+                        for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+                    }
             }
+            PROF_MARK(2);
+        };
+        auto tile_max = [&](int qb) {   // max over the 8 scores a lane holds for query column qb: 3 x v_max3 + 1 x v_max
+            float x = max3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+            x = max3(x, s[qb][0][3], s[qb][1][0]);
+            x = max3(x, s[qb][1][1], s[qb][1][2]);
+            return max2(x, s[qb][1][3]);
+        };
+        auto exp_block = [&](int qb, float msc) {   // p = exp2(s*c - m*c), in place
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[qb][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
+        };
+        auto row_sum = [&](int qb) {    // l += sum of the 8 p a lane holds (in place of s)
+            float x = (s[qb][0][0] + s[qb][0][1]) + (s[qb][0][2] + s[qb][0][3]);
+            x += (s[qb][1][0] + s[qb][1][1]) + (s[qb][1][2] + s[qb][1][3]);
+            lsum[qb] += x;
+        };
+        auto to_bf16 = [&](int qb) {
             bf16x8 pk;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pk[r] = (__bf16)pv[0][r];
-                pk[4 + r] = (__bf16)pv[1][r];
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[kt * 4 + r] = (__bf16)s[qb][kt][r];
+            return pk;
+        };
+        auto pv_mfmas = [&](int tv) {   // O^T += V^T(tv) . P^T(pq): 16 transpose reads + 24 MFMAs
+            const unsigned char *Vb = Vl + (tv % NSTV) * TILE_BYTES;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const int row_a = lg * 4 + (li >> 2);
+                const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
+                const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
+                const s16x4 lo = lds_read_tr16_b64(va);
+                const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
+                const bf16x8 vf = __builtin_bit_cast(
+                    bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vf, pq[qb], o[qb][db]);
             }
-            pb[qb] = pk;
-        }
-
-        // ---- O^T += V^T . P^T ; V^T fragments by transpose-read in the accumulator's k order
+        };
+        if (tend > tbeg) {
+            // ---- first tile: the reference point is its own maximum (exact), nothing to rescale
+            tile_sync(tbeg);
+            qk_tile(tbeg);
 #pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            if (db + VR - 1 < 8) vr[(db + VR - 1) % VR] = load_v(db + VR - 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int qb = 0; qb < 3; ++qb) {
+                m[qb] = max_rows(tile_max(qb));
+                exp_block(qb, m[qb] * SCALE_LOG2E);
+                row_sum(qb);
+                pq[qb] = to_bf16(qb);
+            }
+            PROF_MARK(3);
+            for (int t = tbeg + 1; t < tend; ++t) {
+                tile_sync(t);
+                qk_tile(t);
+                // ---- PV of tile t-1 and the softmax of tile t, hand-interleaved: 8 chunks, each = 3 MFMAs (one 16-wide d
+                // block) + the V^T fragment of the block two ahead + one slice of the softmax, fenced so that the slices
+                // stay in the shadow of MFMAs that do not depend on them (left to itself hipcc runs the whole softmax first
+                // and the MFMAs after it; sched_group_barrier requests did not move it).
+                {
+                    const unsigned char *Vb = Vl + ((t - 1) % NSTV) * TILE_BYTES;
+                    auto load_v = [&](int db) {
+                        const int row_a = lg * 4 + (li >> 2);
+                        const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
+                        const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
+                        const s16x4 lo = lds_read_tr16_b64(va);
+                        const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
+                        return __builtin_bit_cast(
+                            bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                    };
+                    bf16x8 vr[3];
+                    vr[0] = load_v(0), vr[1] = load_v(1);
+                    float mx[3], msc[3];
+                    __builtin_amdgcn_sched_barrier(0);
+                    // chunks 0, 1: maxima; then the (rare) reference update in its own block; chunks 2..7: exp2, row sums
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % VR], pb[qb], o[qb][db]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int db = 0; db < 2; ++db) {
+                        vr[(db + 2) % 3] = load_v(db + 2);
+#pragma unroll
+                        for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
+                        if (db == 0) {
+#pragma unroll
+                            for (int qb = 0; qb < 3; ++qb) {
+                                mx[qb] = tile_max(qb);
+                                pin(mx[qb]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int qb = 0; qb < 3; ++qb) {
+                                mx[qb] = max_rows(mx[qb]);
+                                pin(mx[qb]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;   // the lag in units of the raw scores
+                    if (!__all(mx[0] <= m[0] + LAG_RAW && mx[1] <= m[1] + LAG_RAW && mx[2] <= m[2] + LAG_RAW)) {
+#pragma unroll
+                        for (int qb = 0; qb < 3; ++qb) {
+                            const float m_new = max2(m[qb], mx[qb]);
+                            alpha[qb] = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
+                            lsum[qb] *= alpha[qb];   // (o is rescaled once the pending PV has been accumulated)
+                            m[qb] = m_new;
+                        }
+                    }
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) msc[qb] = m[qb] * SCALE_LOG2E;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int db = 2; db < 8; ++db) {
+                        if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
+#pragma unroll
+                        for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
+                        if (db <= 4) {              // exp2 of one query block per chunk
+                            const int qb = db - 2;
+                            exp_block(qb, msc[qb]);
+                            pin(s[qb][0]);
+                            pin(s[qb][1]);
+                        } else {                    // row sums
+                            const int qb = db - 5;
+                            row_sum(qb);
+                            pin(lsum[qb]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // P^T of tile t as bf16: only once the last MFMA on tile t-1's P has been issued (a second set of P
+                    // registers would push the kernel over 256 VGPRs)
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) pq[qb] = to_bf16(qb);
+                }
+                PROF_MARK(3);
+                // rescale AFTER the pending PV has been accumulated: O_t = alpha_t (O_{t-1} + P_{t-1} V_{t-1}) + P_t V_t
+                if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f && alpha[2] == 1.0f)) {
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) {
+#pragma unroll
+                        for (int db = 0; db < 8; ++db) o[qb][db] *= alpha[qb];
+                        alpha[qb] = 1.f;
+                    }
+                }
+                PROF_MARK(4);
+            }
+            pv_mfmas(tend - 1);
         }
     }
+    PROF_END(w, tend - tbeg);
 
     if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
@@ -582,11 +720,11 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *counts, 
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 int launch_attn(const AttnParams &p, hipStream_t stream) {
     auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY>;
-    constexpr int LDS = ATTN_LDS_BYTES - (CSONLY ? NST * TILE_BYTES : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const int LDS = chipmunk_get_option("attn_pp") == 1 ? 96 * 1024 : ATTN_LDS_BYTES - (CSONLY ? NSTV * TILE_BYTES : 0);
+    static int attr_set = 0;
+    if (attr_set != LDS) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+        attr_set = LDS;
     }
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
@@ -594,6 +732,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
              "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
     AttnParams pp = p;
     pp.probe = chipmunk_get_option("attn_variant");
+    // experiment knob: attn_pp = 1 requests enough LDS that only ONE workgroup fits a CU (one wave per SIMD)
+    const int wg_per_cu = chipmunk_get_option("attn_pp") == 1 ? 1 : 2;
     // block -> XCD mapping: 1 = every XCD walks its own contiguous (head, group) range, 0 = all XCDs sweep one head
     // together; option value 2 = chunks for the gathered launches only
     const int xo = chipmunk_get_option("attn_xcd_chunks");
@@ -602,8 +742,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     constexpr size_t TICKET_BYTES = 64 << 10;
     int64_t grid = nblocks;
     if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768) && !chipmunk_get_option("attn_no_order")) {
-        const int slots = 2 * device_cu_count();
-        const int max_slices = 3 * slots;                         // 1536 x 104 KB = 160 MB of partials at most
+        const int slots = wg_per_cu * device_cu_count();
+        const int max_slices = 3 * 2 * device_cu_count();         // 1536 x 104 KB = 160 MB of partials at most
         const int64_t cap = nblocks + max_slices;                 // plan entries == workgroups launched
         const size_t plan_bytes = (size_t)cap * 2 * sizeof(int32_t);
         const size_t ws_off = (TICKET_BYTES + plan_bytes + 255) & ~(size_t)255;
@@ -627,7 +767,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // again, and the split measured 94 -> 105 us there (option attn_split_gather forces it, for the tests).
     if (!CSONLY && !pp.plan && !pp.xcd_chunks && !chipmunk_get_option("attn_no_split") &&
         (!GATHER || chipmunk_get_option("attn_split_gather"))) {
-        const int64_t slots = 2 * (int64_t)device_cu_count();
+        const int64_t slots = wg_per_cu * (int64_t)device_cu_count();
         const int64_t rem = nblocks <= slots / 2 ? nblocks : nblocks % slots;
         if (rem > 0 && rem * 2 <= slots && rem * sizeof(int32_t) <= TICKET_BYTES) {
             int f = (int)(slots / rem);

@@ -7,7 +7,7 @@ Attention inputs have planted structure (tests/helpers.py: structured_qkv): the 
 noise-floor filler, so implementations that round the bf16 column sums / break top-k ties differently (torch.topk on
 CPU vs the HIP top-k, fp32 vs bf16 partial sums) still agree on every output to bf16 precision, while a wrapper mistake
 (cache sign, padding, a stale mask, `l` not zeroed) moves the output by O(|o|).  Tolerance per element:
-``4e-3 + 2e-2 * |ref|`` (|o| ~ 0.1-0.4); hot sets asserted bit-exact inside the kept sets; FLUX counts bit-exact.
+``6e-3 + 2e-2 * |ref|`` (|o| ~ 0.1-0.4; three bf16 roundings of values near 0.4 lie between the two pipelines); hot sets asserted bit-exact inside the kept sets; FLUX counts bit-exact.
 The CPU half of the file checks the mirror against the same fixture with the oracle-backed ops (bit-exact)."""
 import os
 
@@ -32,7 +32,7 @@ def _check(t, d, what, exact):
         assert torch.equal(got, want), what
         return
     err = (got - want).abs()
-    tol = 4e-3 + 2e-2 * want.abs()
+    tol = 6e-3 + 2e-2 * want.abs()
     assert not (err > tol).any(), f"{what}: {int((err > tol).sum())} of {err.numel()} sampled elements off, max abs diff {err.max():.4g} (|ref| max {want.abs().max():.3g})"
     rel = abs(t.double().abs().sum().item() - d["abs"]) / d["abs"]
     assert rel < 5e-3, f"{what}: sum |o| off by {rel:.3%}"
