@@ -810,6 +810,45 @@ extern "C" int chipmunk_transpose16(const void *src, void *dst, int B, int R, in
     return CHIPMUNK_OK;
 }
 
+// =====================================================================================  token reorder (row gather)
+// The reference reorders tokens with einops / slicing chains under torch.compile (ops/patch.py:7-80: FLUX two-level
+// patch order; ops/voxel.py:9-99: HunyuanVideo / Wan (4,6,8) voxel order with three tail regions, and their inverses).
+// Every one of them is a fixed permutation of the token axis, so here it is ONE gather: dst[o, i, :] = src[o, map[i], :]
+// with the permutation precomputed once per shape on the host side (chipmunk_amd/ops/_reorder.py) -- one pass at HBM
+// rate instead of a reshape / permute / cat / index_put chain (HunyuanVideo: 118 800 rows of 6 KB per direction and step).
+template <typename V>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const V *src, V *dst, const int32_t *map, int64_t n_out,
+                                                          int64_t n_src, int64_t cpr, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / cpr, c = idx - row * cpr;
+        const int64_t o = row / n_out, r = row - o * n_out;
+        dst[idx] = src[(o * n_src + map[r]) * cpr + c];
+    }
+}
+
+extern "C" int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t outer, int64_t n_src,
+                                    int64_t n_out, int64_t row_bytes, void *stream) {
+    CM_CHECK(src && dst && map, "gather_rows: null pointer");
+    CM_CHECK(outer >= 0 && n_src > 0 && n_out >= 0 && row_bytes > 0, "gather_rows: bad sizes");
+    if (outer == 0 || n_out == 0) return CHIPMUNK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const uintptr_t align = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)row_bytes;
+#define LAUNCH_GATHER(V)                                                                                              \
+    do {                                                                                                              \
+        const int64_t cpr = row_bytes / (int64_t)sizeof(V), total = outer * n_out * cpr;                               \
+        const int64_t blocks = (total + 255) / 256;                                                                    \
+        hipLaunchKernelGGL((gather_rows_kernel<V>), dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)),       \
+                           dim3(256), 0, s, (const V *)src, (V *)dst, map, n_out, n_src, cpr, total);                  \
+    } while (0)
+    if ((align & 15) == 0) LAUNCH_GATHER(u32x4);
+    else if ((align & 3) == 0) LAUNCH_GATHER(uint32_t);
+    else if ((align & 1) == 0) LAUNCH_GATHER(uint16_t);
+    else LAUNCH_GATHER(uint8_t);
+#undef LAUNCH_GATHER
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
 extern "C" int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void *static_mask, int64_t static_stride,
                                   int static_rows, const void *group_flags, void *mask, int rows, int n, int k,
                                   double random_amount, void *stream) {

@@ -501,6 +501,26 @@ at::Tensor bitunpack(at::Tensor packed, at::IntArrayRef shape) {
     return mask;
 }
 
+// dst[..., i, :] = src[..., map[i], :] over the second-to-last axis (token reorder; see chipmunk_gather_rows)
+at::Tensor gather_rows(at::Tensor src, at::Tensor map) {
+    CHECK_DEV(src);
+    CHECK_DEV(map);
+    TORCH_CHECK(src.dim() >= 2, "gather_rows: src must be [..., n, d]");
+    TORCH_CHECK(map.scalar_type() == at::kInt && map.dim() == 1 && map.is_contiguous(), "gather_rows: map must be a contiguous int32 vector");
+    src = src.contiguous();
+    const int64_t n_src = src.size(-2), d = src.size(-1), n_out = map.numel();
+    const int64_t outer = n_src * d == 0 ? 0 : src.numel() / (n_src * d);
+    auto sizes = src.sizes().vec();
+    sizes[sizes.size() - 2] = n_out;
+    c10::DeviceGuard guard(src.device());
+    at::Tensor dst = at::empty(sizes, src.options());
+    if (dst.numel() == 0) return dst;
+    check(chipmunk_gather_rows(src.data_ptr(), dst.data_ptr(), map.data_ptr<int>(), outer, n_src, n_out,
+                               d * (int64_t)src.element_size(), cur_stream(src)),
+          "gather_rows");
+    return dst;
+}
+
 }  // namespace
 
 // schemas: byte-identical to reference csrc/chipmunk.cpp:47-60 (including its un-annotated mutations of `o`,
@@ -531,6 +551,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
+    m.def("gather_rows(Tensor src, Tensor map) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
@@ -555,6 +576,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("transpose_last2", &transpose_last2);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);
+    m.impl("gather_rows", &gather_rows);
 }
 
 }  // namespace chipmunk

@@ -153,10 +153,12 @@ class SparseDiffAttn(nn.Module):
             if not cfg["recompute_mask"]:
                 inds, counts = self._stored_indices(multiple_of, bm)
 
-            if do_padding:
-                o_cache = o - ops.csp_attn(q, k, v, inds, counts)
-            elif o.is_cuda and cfg.get("fused_residual", True):
+            if o.is_cuda and cfg.get("fused_residual", True):
+                # dense - sparse in the attention kernel's epilogue (bf16(o - bf16(sparse)), the same two roundings as the
+                # reference's `o - csp_attn(...)`), no 731 MB intermediate at HunyuanVideo size
                 o_cache = ops.csp_attn_out(q, k, v, o, inds, counts, -1)
+            elif do_padding:
+                o_cache = o - ops.csp_attn(q, k, v, inds, counts)
             else:
                 o_cache = o.clone()
                 ops.csp_attn_inplace(q, k, v, o_cache, inds, counts, -1)
@@ -167,6 +169,8 @@ class SparseDiffAttn(nn.Module):
         inds, counts = self._stored_indices(multiple_of, bm)
         o = self.storage.get_out_cache()
         if do_padding:
+            if o.is_cuda and cfg.get("fused_residual", True):
+                return ops.csp_attn_out(q, k, v, o, inds, counts, 1)   # cache + delta in one kernel; the cache is only read
             return o + ops.csp_attn(q, k, v, inds, counts)
         # Is `o` the persistent cache itself, or a pipeline slot that the next load overwrites from the host copy?  The
         # reference decides on the config flag (attn.py:186-188) because there a flagged tensor always lives on the host;

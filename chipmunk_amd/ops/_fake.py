@@ -52,5 +52,11 @@ def _register():
     def _(packed, shape):
         return packed.new_empty(tuple(shape), dtype=torch.bool)
 
+    @lib.register_fake("chipmunk::gather_rows")
+    def _(src, map):
+        shape = list(src.shape)
+        shape[-2] = map.shape[0]
+        return src.new_empty(shape)
+
 
 _register()

@@ -11,11 +11,19 @@ from typing import Sequence
 import torch
 
 from ..util.config import GLOBAL_CONFIG
+from . import _reorder
 
 
 def _chunks():
     cfg = GLOBAL_CONFIG["patchify"]
     return int(cfg["chunk_size_1"]), int(cfg["chunk_size_2"])
+
+
+def _patchify_torch(x: torch.Tensor, c1: int, c2: int) -> torch.Tensor:
+    b, h, w = x.shape
+    s = c1 // c2
+    x7 = x.reshape(b, h // c1, s, c2, w // c1, s, c2)
+    return x7.permute(0, 1, 4, 2, 5, 3, 6).reshape(b, h * w)
 
 
 def patchify(x: torch.Tensor) -> torch.Tensor:
@@ -28,10 +36,11 @@ def patchify(x: torch.Tensor) -> torch.Tensor:
     assert h % c2 == 0, "Height must be divisible by chunk_size_2."
     assert w % c2 == 0, "Width must be divisible by chunk_size_2."
     assert c1 % c2 == 0, "chunk_size_1 must be divisible by chunk_size_2."
-    s = c1 // c2
+    if x.is_cuda:   # one gather with the cached permutation
+        m = _reorder.index_map(("patchify", h, w, c1, c2), h * w, x.device, lambda i: _patchify_torch(i.view(1, h, w), c1, c2))
+        return _reorder.gather_rows(x.reshape(b, h * w, 1), m).reshape(b, h * w)
     # row = (ph, sh, r), col = (pw, sw, c)
-    x7 = x.reshape(b, h // c1, s, c2, w // c1, s, c2)
-    return x7.permute(0, 1, 4, 2, 5, 3, 6).reshape(b, h * w)
+    return _patchify_torch(x, c1, c2)
 
 
 def unpatchify(x_chunk_flat: torch.Tensor, original_shape: Sequence[int]) -> torch.Tensor:
@@ -39,6 +48,10 @@ def unpatchify(x_chunk_flat: torch.Tensor, original_shape: Sequence[int]) -> tor
     c1, c2 = _chunks()
     b, h, w = original_shape
     s = c1 // c2
+    if x_chunk_flat.is_cuda:
+        m = _reorder.index_map(("patchify", h, w, c1, c2), h * w, x_chunk_flat.device,
+                               lambda i: _patchify_torch(i.view(1, h, w), c1, c2), inverse=True)
+        return _reorder.gather_rows(x_chunk_flat.reshape(b, h * w, 1), m).reshape(b, h, w)
     x7 = x_chunk_flat.reshape(b, h // c1, w // c1, s, s, c2, c2)
     return x7.permute(0, 1, 3, 5, 2, 4, 6).reshape(b, h, w)
 

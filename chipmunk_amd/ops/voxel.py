@@ -22,6 +22,17 @@ def _split(x: torch.Tensor, voxel_shape: Sequence[int]):
 def voxel_chunk_no_padding(x: torch.Tensor, voxel_shape: Sequence[int] = (4, 4, 4)) -> torch.Tensor:
     """[b, ah, t, h, w, d] -> [b, ah, t*h*w, d]: full voxels first (voxel raster order, raster inside each voxel),
     then the t-tail, the h-tail and the w-tail in raster order."""
+    if x.is_cuda:   # one gather with the cached permutation (SURVEY 8f rank 3)
+        from . import _reorder
+        b, ah, t, h, w, d = x.shape
+        vs = tuple(int(v) for v in voxel_shape)
+        m = _reorder.index_map(("voxel", t, h, w, vs), t * h * w, x.device,
+                               lambda i: _voxel_chunk_torch(i.view(1, 1, t, h, w, 1), vs))
+        return _reorder.gather_rows(x.reshape(b, ah, t * h * w, d), m)
+    return _voxel_chunk_torch(x, voxel_shape)
+
+
+def _voxel_chunk_torch(x: torch.Tensor, voxel_shape: Sequence[int]) -> torch.Tensor:
     b, ah, t, h, w, d = x.shape
     vt, vh, vw = voxel_shape
     tf, hf, wf = _split(x, voxel_shape)
@@ -41,6 +52,12 @@ def reverse_voxel_chunk_no_padding(x_chunk_flat: torch.Tensor, original_shape: S
                                    voxel_shape: Sequence[int] = (4, 4, 4)) -> torch.Tensor:
     """Inverse of :func:`voxel_chunk_no_padding`."""
     b, ah, t, h, w, d = original_shape
+    if x_chunk_flat.is_cuda:
+        from . import _reorder
+        vs = tuple(int(v) for v in voxel_shape)
+        m = _reorder.index_map(("voxel", t, h, w, vs), t * h * w, x_chunk_flat.device,
+                               lambda i: _voxel_chunk_torch(i.view(1, 1, t, h, w, 1), vs), inverse=True)
+        return _reorder.gather_rows(x_chunk_flat.reshape(b, ah, t * h * w, d), m).reshape(b, ah, t, h, w, d)
     vt, vh, vw = voxel_shape
     tf, hf, wf = (t // vt) * vt, (h // vh) * vh, (w // vw) * vw
     out = torch.zeros(tuple(original_shape), dtype=x_chunk_flat.dtype, device=x_chunk_flat.device)

@@ -191,6 +191,14 @@ int chipmunk_transpose16(const void *src, void *dst, int B, int R, int C, void *
 int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream);
 int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------- token reorder
+ * dst[o, i, :] = src[o, map[i], :] for o < outer, i < n_out; rows of `row_bytes` bytes, src has n_src rows per outer
+ * index.  One gather for each of the reference's token reorders -- patchify / unpatchify / patchify_rope
+ * (src/chipmunk/ops/patch.py:7-80) and voxel_chunk_no_padding / reverse_voxel_chunk_no_padding
+ * (src/chipmunk/ops/voxel.py:9-99) -- whose permutations the host side computes once per shape. `map` int32 [n_out]. */
+int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t outer, int64_t n_src, int64_t n_out,
+                         int64_t row_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
