@@ -427,6 +427,31 @@ class Hunyuan:
         return {"top_keys": top_keys, "mean_kept_keys": mc, "column_sparsity": None if mc is None else 1.0 - mc / self.N,
                 "mask_step_s": times[0][2], "sparse_step_s": sum(t for _, _, t in times[1:]) / max(1, len(times) - 1)}
 
+    def offload_report(self, sparse_step_s):
+        """--offload: what crosses PCIe per sparse step (every block's 731 MB cache + 222 MB packed mask come back from
+        pinned host memory, SURVEY 8a storage row), the rate that needs, and the measured pinned-copy rates of this box."""
+        a = next((l[0][0] for l in self.layers if l[0][0].storage.out_cache.cpu_buf[0] is not None), None)
+        if a is None:
+            return None
+        per_layer = sum(b.numel() * b.element_size() for b in (a.storage.out_cache.cpu_buf[0], a.storage.indices.cpu_buf[0]) if b is not None)
+        n_sparse_layers = sum(1 for l in self.layers if l[0][0].storage.out_cache.cpu_buf[0] is not None)
+        host = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+        devb = torch.empty(1 << 30, dtype=torch.uint8, device=self.dev)
+        rates = {}
+        for name, (dst, src) in (("h2d", (devb, host)), ("d2h", (host, devb))):
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                dst.copy_(src, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            rates[name + "_GBps"] = 4 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        return {"h2d_bytes_per_sparse_step": per_layer * n_sparse_layers, "layers_offloaded": n_sparse_layers,
+                "h2d_GBps_needed_to_hide": per_layer * n_sparse_layers / sparse_step_s / 1e9, **rates,
+                "what": "copies ride two side streams (hipMemcpyAsync from hipHostMalloc memory), one block ahead of the compute"}
+
     def desc(self):
         return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": HunyuanVideo 720x1280x129, {self.n_img} image + "
                 f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {self.n_layers} blocks (first 2 dense)",
@@ -589,6 +614,8 @@ def main():
         extra["timed_steps"] = {"inference_steps": [s for s, _, _ in timed_times],
                                 "kinds": {k: sum(1 for _, kk, _ in timed_times if kk == k) for k in kinds},
                                 "mean_step_s_by_kind (warm-up steps included)": {k: round(v, 4) for k, v in mean.items()}}
+        if args.offload and rank == 0 and "sparse" in mean:
+            extra["offload"] = wl.offload_report(mean["sparse"])
         extra["mean_kept_keys_per_group"] = mc
         extra["column_sparsity"] = None if mc is None else round(1.0 - mc / wl.N, 4)
         if all(k in mean for k in ("dense0", "mask", "sparse")):

@@ -237,3 +237,91 @@ def test_sliced_heavy_items_match_unsliced_and_oracle(H):
     inpl = base.clone().to(dev)
     torch.ops.chipmunk.csp_attn(qd, kd, vd, inpl, indd, cntd, -1)
     assert torch.equal(inpl, out), "in-place and out-of-place accumulate agree bit for bit"
+
+
+# ------------------------------------------------------------------------------------------------ config-sized cases
+def test_c2_flux_attention_full_size_all_heads(dev):
+    """BASELINE configs[1] at its real size: 24 heads, 4352 tokens, 672 kept keys per 192-query group, in-place delta
+    kernel.  Heads 0, 11 and 23 against the oracle; every head through the cache identity (o - sparse) + sparse == o up to
+    the two bf16 roundings; and `csp_attn_out` == clone + in-place, bit for bit."""
+    from helpers import random_index_sets
+    H, N, count = 24, 4352, 672
+    G = math.ceil(N / 192)
+    q, k, v = [randn_bf16(1, H, N, 128, seed=s) for s in (31, 32, 33)]
+    inds, counts = random_index_sets(1, H, G, N, count, N, seed=34, multiple_of=112)
+    base = randn_bf16(1, H, N, 128, seed=35)
+    qd, kd, vd, indd, cntd = [t.to(dev) for t in (q, k, v, inds, counts)]
+    o = base.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, o, indd, cntd, -1)
+    for h in (0, 11, 23):
+        ref = base[:, h:h + 1].clone()
+        oracle.csp_attn(q[:, h:h + 1].contiguous(), k[:, h:h + 1].contiguous(), v[:, h:h + 1].contiguous(), ref,
+                        inds[:, h:h + 1].contiguous(), counts[:, h:h + 1].contiguous(), -1)
+        assert_close_bf16(o[:, h:h + 1], ref, what=f"C2 csp_attn head {h} vs oracle")
+    out = torch.ops.chipmunk.csp_attn_out(qd, kd, vd, base.to(dev), indd, cntd, -1)
+    assert torch.equal(out, o)
+    back = o.clone()
+    torch.ops.chipmunk.csp_attn(qd, kd, vd, back, indd, cntd, 1)
+    assert_close_bf16(back, base, atol=2e-2, rtol=2e-2, what="C2 (o - sparse) + sparse")
+
+
+def test_c5_wan_fp8_gemm1_full_size(dev):
+    """BASELINE configs[4] shapes: Wan2.1-1.3B MLP, M = 32 768 rows, K = 1536, F = 8960, 30 % of the columns kept per
+    128-row group, fp8 e4m3 operands.  Four row groups are checked against fp32 torch math on the dequantised operands
+    (gelu_tanh((a8 . b8[idx]) * sa * sb + bias) - cache); columns past the count and un-selected cache columns untouched."""
+    M, K, F = 32768, 1536, 8960
+    keep = 2816                                         # 0.3 * 8960 rounded up to a multiple of 256
+    g = torch.Generator(device=dev).manual_seed(51)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(F, K, device=dev, generator=g) * 0.05
+    sa, sb = 448.0 / x.abs().max(), 448.0 / w.abs().max()
+    a8, b8 = (x * sa).to(torch.float8_e4m3fn), (w * sb).to(torch.float8_e4m3fn)
+    bias = (torch.randn(F, device=dev, generator=g) * 0.2).to(torch.bfloat16)
+    cache = (torch.randn(F, M, device=dev, generator=g) * 0.3).to(torch.bfloat16)
+    cache0 = cache.clone()
+    Gm = M // 128
+    inds = torch.stack([torch.randperm(F, device=dev, generator=g) for _ in range(Gm)]).to(torch.int32)
+    counts = torch.full((Gm,), keep, dtype=torch.int32, device=dev)
+    counts[7] = 0
+    counts[100] = 256
+    packed = torch.full((M, F), 7.0, dtype=torch.bfloat16, device=dev)
+    ra, rb = (1.0 / sa).reshape(1).float(), (1.0 / sb).reshape(1).float()
+    torch.ops.chipmunk.csp_mlp_mm1_fp8(a8, b8, packed, bias, cache, inds, counts, ra, rb, True)
+    for gi in (0, 7, 100, Gm - 1):
+        rows = slice(gi * 128, (gi + 1) * 128)
+        n = int(counts[gi])
+        cols = inds[gi, :n].long()
+        acc = (a8[rows].float() @ b8[cols].float().T) * ra * rb + bias[cols].float()
+        act = torch.nn.functional.gelu(acc, approximate="tanh").to(torch.bfloat16)
+        want = (act.float() - cache0[cols][:, rows].float().T).to(torch.bfloat16)
+        assert_close_bf16(packed[rows, :n], want, atol=3e-2, rtol=3e-2, what=f"C5 fp8 GEMM1 group {gi}")
+        assert (packed[rows, n:] == 7.0).all(), "columns past the count are not written"
+        assert_close_bf16(cache[cols][:, rows], act.T, atol=3e-2, rtol=3e-2, what=f"C5 cache update group {gi}")
+        rest = inds[gi, n:].long()
+        assert torch.equal(cache[rest][:, rows], cache0[rest][:, rows]), "unselected cache columns keep their bits"
+
+
+def test_c5_wan_attention_shapes(dev):
+    """Wan2.1 832x480x81: 12 heads, 32 760 tokens (171 query groups, the last one ragged).  Dense vs SDPA on two row
+    slices; sparse with identity lists == dense; sparse with random 10 % lists: one group per head against the oracle."""
+    H, N = 12, 32760
+    G = math.ceil(N / 192)
+    g = torch.Generator(device=dev).manual_seed(61)
+    q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
+    o_dense, l = torch.ops.chipmunk.dense_attn(q, k, v)
+    for rows in (slice(0, 384), slice(N - 300, N)):
+        ref = torch.nn.functional.scaled_dot_product_attention(q[:, :, rows].float(), k.float(), v.float())
+        assert_close_bf16(o_dense[:, :, rows], ref, atol=1e-2, rtol=2e-2, what="Wan dense vs SDPA")
+    count = 3328
+    inds = torch.zeros(1, H, G, G * 192, dtype=torch.int32, device=dev)
+    for h in range(H):
+        r = torch.rand(G, N, device=dev, generator=g)
+        inds[0, h, :, :count] = r.topk(count, dim=-1).indices.sort(dim=-1).values.to(torch.int32)
+    counts = torch.full((1, H, G), count, dtype=torch.int32, device=dev)
+    o = torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts)
+    qc, kc, vc, ic = q.cpu(), k.cpu(), v.cpu(), inds.cpu()
+    for h, gi in ((0, 0), (5, 77), (11, G - 1)):
+        r0, r1 = gi * 192, min(N, gi * 192 + 192)
+        ref = oracle.csp_128_attn(qc[:, h:h + 1, r0:r1].contiguous(), kc[:, h:h + 1].contiguous(), vc[:, h:h + 1].contiguous(),
+                                  ic[:, h:h + 1, gi:gi + 1, :N].contiguous(), counts[:, h:h + 1, gi:gi + 1].cpu().contiguous())
+        assert_close_bf16(o[:, h:h + 1, r0:r1], ref, what=f"Wan sparse head {h} group {gi} vs oracle")
