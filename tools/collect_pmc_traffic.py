@@ -35,8 +35,26 @@ def one_pass(counter, what, extra_env=None):
     return {k: sum(v.values()) / len(v) for k, v in per.items()}
 
 
+C3_KERNELS = {  # HunyuanVideo shapes (bench.py workload hunyuan_c3): kbench cases with all 24 heads
+    "csp_128_attn_c3": "attn_kernel<true, true", "dense_attn_c3": "attn_kernel<false, false, true, false>",
+    "colsum_pass_c3": "attn_kernel<false, false, false, true>",
+}
+
+
 def main(tag):
     res = {}
+    c3_env = {"KB_HEADS": "24", "KB_COUNT_C3": "9088"}
+    fetch, write = one_pass("FETCH_SIZE", ["csp_hunyuan", "colsum_hunyuan"], c3_env), one_pass("WRITE_SIZE", ["csp_hunyuan", "colsum_hunyuan"], c3_env)
+    for key, pat in C3_KERNELS.items():
+        f = [v for k, v in fetch.items() if pat in k]
+        w = [v for k, v in write.items() if pat in k]
+        if f and w:
+            res[key] = {"FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB_raw": w[0], "hbm_bytes_per_launch": (2.0 * f[0] + w[0]) * 1024.0,
+                        "note": "24 heads x 119 056 tokens; sparse: 9 088 sorted random keys per 192-query group (the bench's mean "
+                                "count), in-place accumulate form; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE uncorrected"}
+    if "dense_attn_c3" in res and "colsum_pass_c3" in res:
+        res["dense_colsum_attn_c3"] = {"hbm_bytes_per_launch": res["dense_attn_c3"]["hbm_bytes_per_launch"] + res["colsum_pass_c3"]["hbm_bytes_per_launch"],
+                                       "note": "dense pass + K-only column-sum pass"}
     for what, keys, fused in ((["mm1", "mm2", "scatter", "csp_flux", "dense_flux"], list(KERNELS), False),
                               (["mm1s"], ["mm1"], True)):
         fetch, write = one_pass("FETCH_SIZE", what), one_pass("WRITE_SIZE", what)
