@@ -74,3 +74,22 @@ def test_gather_rows_is_traceable(dev):
         m = torch.empty(40, dtype=torch.int32, device="cuda")
         out = torch.ops.chipmunk.gather_rows(src, m)
         assert out.shape == (2, 3, 40, 64) and out.dtype == torch.bfloat16
+
+
+def test_ops_trace_under_dynamo_without_graph_breaks(dev):
+    """Reference ops have no fake kernels, so torch.compile graph-breaks at every one; here a sparse
+    attention step traces as ONE graph (fullgraph=True; backend "eager": tracing and fake-tensor propagation only)."""
+    import math
+    from helpers import randn_bf16, random_index_sets
+    H, n, count = 2, 768, 256
+    q, k, v, base = [randn_bf16(1, H, n, 128, seed=s).to(dev) for s in (1, 2, 3, 4)]
+    inds, counts = [t.to(dev) for t in random_index_sets(1, H, math.ceil(n / 192), n, count, n, seed=5)]
+
+    def step(q, k, v, base, inds, counts):
+        o = torch.ops.chipmunk.csp_attn_out(q, k, v, base, inds, counts, 1)
+        d, l = torch.ops.chipmunk.dense_attn(q, k, v)
+        return o + d, l
+
+    eager = step(q, k, v, base, inds, counts)
+    compiled = torch.compile(step, backend="eager", fullgraph=True)(q, k, v, base, inds, counts)
+    assert torch.equal(eager[0], compiled[0]) and torch.equal(eager[1], compiled[1])
