@@ -186,10 +186,17 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 z = {};
             qf[qb][ks] = (qrow < p.Nq && !(p.probe & 8)) ? *(const bf16x8 *)(qp + ks * 32 + lg * 8) : z;
+            if constexpr (CSONLY) {
+                // column-sum pass: q * (log2e / sqrt(D)) rounded to bf16 once per item, so the scores leave the MFMA in
+                // the exp2 domain and -- with log2(prev_l) as the accumulator's initial value -- need no per-score fma
+                // (the sums only rank columns and are stored as bf16: one more bf16 rounding of q is far inside that)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)qf[qb][ks][e] * SCALE_LOG2E);
+            }
         }
     }
 
-    float cs_off[3][4];  // CSONLY: log2(prev_l) of query row qb*16 + lg*4 + r (that pass computes S, not S^T)
+    f32x4 cs_off[3];  // CSONLY: log2(prev_l) of query rows qb*16 + lg*4 + 0..3 (that pass computes S, not S^T)
     if constexpr (CSONLY) {
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
@@ -197,7 +204,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             for (int r = 0; r < 4; ++r) {
                 const int qr = row0 + qb * 16 + lg * 4 + r;
                 const float pl = qr < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
-                cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -INFINITY;
+                // (rows past Nq and rows with prev_l == 0 contribute exp2(-huge) = 0; a finite value keeps 0 * -inf away)
+                cs_off[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -1.0e30f;
             }
         for (int i = tid; i < 2 * 2 * 4 * KVT; i += 256) cs_acc[i] = 0.f;
     }
@@ -265,10 +273,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         auto cs_tile = [&](int t, int it) {
             const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
             f32x4 s[3][2];
-#pragma unroll
-            for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             auto load_k = [&](int idx) {
                 const int kt = idx >> 2, ks = idx & 3;
                 const int pc = (ks * 4 + lg) ^ li;
@@ -281,8 +285,9 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 if (idx + 2 < 8) kr[(idx + 2) % 3] = load_k(idx + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 const int kt = idx >> 2, ks = idx & 3;
+                // S*c + log2(prev_l) = (Q*c) . K^T accumulated on top of log2(prev_l)
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(qf[qb][ks], kr[idx % 3], s[qb][kt]);  // S = Q . K^T
+                for (int qb = 0; qb < 3; ++qb) s[qb][kt] = mfma16(qf[qb][ks], kr[idx % 3], ks == 0 ? cs_off[qb] : s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // exp2(s*c + log2 prev_l), summed over this wave's 48 queries: 12 in-lane terms, then the 4 lane rows
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        a += __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, cs_off[qb][r]));
+                        a += __builtin_amdgcn_exp2f(s[qb][kt][r]);
                 cacc[kt] = t * KVT + kt * 16 + li < valid ? a : 0.f;
             }
             lane_swap32(cacc[0], cacc[1]);      // [0] = {kt0 rows 0-1, kt1 rows 0-1}, [1] = {kt0 rows 2-3, kt1 rows 2-3}
