@@ -229,3 +229,48 @@ def test_packed_positions_past_the_key_count_are_masked(dev):
     assert_close_bf16(o, o_ref, what="right_fill")
     sdpa = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
     assert_close_bf16(o, sdpa, what="right_fill == attention over all nk keys")
+
+
+@pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
+def test_running_max_update_paths(dev, pattern):
+    """The kernel's exponentials are taken against a reference point that lags the running row maximum by up to 2^4 and
+    is raised (with a rescale of O and l once the pending PV has landed) only when some query column outgrows the lag.
+    Bounded random data almost never takes that branch, so force it: scores that grow tile after tile ("ramp"), one
+    key far above everything late in the list for SOME query rows only ("spike"), the same in the very first tile, and
+    scores that only shrink ("descending": the branch must never be needed).  Dense and gathered kernels vs the oracle,
+    `l` included (it carries the reference point)."""
+    n, H = 1152, 2
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, H, n, 128, generator=g)
+    k = torch.randn(1, H, n, 128, generator=g)
+    v = torch.randn(1, H, n, 128, generator=g)
+    u = torch.randn(128, generator=g)
+    u = u / u.norm()
+    q = 0.3 * q + 3.0 * u                      # every query has a component along u ...
+    if pattern == "ramp":                      # ... and key j has a growing one: scores rise by ~0.25 nats per 32-key tile
+        k = 0.3 * k + (torch.arange(n).float() / n * 30.0)[None, None, :, None] * u
+    elif pattern == "descending":
+        k = 0.3 * k + ((n - torch.arange(n)).float() / n * 30.0)[None, None, :, None] * u
+    else:
+        k = 0.3 * k
+        j = 5 if pattern == "spike_first" else 1000
+        k[0, :, j] += 40.0 * u                 # q.k/sqrt(128) ~ +10 nats for the rows below
+        q[0, :, ::3] *= 0.05                   # two thirds of the rows see it, the others barely: lanes of one wave disagree
+    q, k, v = [t.to(torch.bfloat16) for t in (q, k, v)]
+    o_ref, l_ref = oracle.dense_attn(q, k, v)
+    o, l = torch.ops.chipmunk.dense_attn(q.to(dev), k.to(dev), v.to(dev))
+    assert_close_bf16(o, o_ref, what=f"dense, {pattern}")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=2e-3, atol=0)
+    G = math.ceil(n / 192)
+    inds = torch.arange(n, dtype=torch.int32).expand(1, H, G, n).contiguous()
+    counts = torch.full((1, H, G), n, dtype=torch.int32)
+    o2 = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o2, o_ref, what=f"gathered with identity lists, {pattern}")
+    # a gathered list that visits the keys in DEscending score order for the ramp = only the first tile sets the reference
+    rev = torch.arange(n - 1, -1, -1, dtype=torch.int32).expand(1, H, G, n).contiguous()
+    o3 = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), rev.to(dev), counts.to(dev))
+    assert_close_bf16(o3, o_ref, what=f"gathered in reverse key order, {pattern}")
+    base = randn_bf16(1, H, n, 128, seed=3)
+    acc = base.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), acc, inds.to(dev), counts.to(dev), 1)
+    assert_close_bf16(acc, (base.float() + o_ref.float()).to(torch.bfloat16), what=f"in-place accumulate, {pattern}")
