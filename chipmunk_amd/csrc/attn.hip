@@ -17,8 +17,6 @@
 //   * scheduling across workgroups: longest-first order for ragged key counts, key-split tail with a last-arriver merge
 //     for near-equal items (see launch_attn); no float atomics, every reduction has a fixed order.
 #include "common.h"
-#include <type_traits>
-#include <utility>
 
 namespace {
 
@@ -645,529 +643,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 }
 
-// ======================================================================================================================
-// One-wave-per-SIMD form of the main loop ("W96"): a workgroup is TWO waves of 96 query rows each (one 192-row group),
-// two workgroups per CU, so every wave owns a SIMD and its whole 512-entry register file.
-//
-// Why (tools/attn_prof.py, DESIGN.md 4.1): at two waves per SIMD a tile costs ~3150 cycles per 96 query rows against
-// ~1550 of matrix-pipe time -- exposed latencies, and a 256-register budget that blocks the remaining VALU savings.  With
-// 96 rows per wave the K / V fragments are read from LDS once per 96 rows instead of once per 48, the 102 MFMAs of a tile
-// carry the ~170 VALU instructions of the same wave in their shadow, and the register file holds what the 4-wave kernel
-// cannot:  (a) Q pre-scaled by log2e/sqrt(D) -- the scores leave the
-// matrix pipe as s*c and the softmax is max -> sub -> exp2 -> sum -> bf16 with no multiply per score;  (b) a
-// second P^T buffer, so the bf16 conversion of tile t also sits in the shadow of the PV MFMAs of tile t-1.
-// hipcc cannot allocate such a kernel (it shuttles values between the two halves of the register file with 600+
-// v_accvgpr moves per tile), so the MFMA-only state lives in ACCUMULATOR REGISTERS NAMED BY HAND and is touched by inline
-// asm only:   a[0:191]   O^T accumulators, block (qb, db) at a[(qb*8+db)*4 .. +3]
-//             a[192:255] the pre-scaled Q^T fragments of query blocks 2..5 (B operands of their QK^T MFMAs)
-// -- the WHOLE accumulator half, so the compiler has nowhere to spill but scratch (which the audit forbids): it uses
-// accumulator registers as spill space on its own whenever it runs out of VGPRs, clobber lists notwithstanding.
-// Everything VALU touches (scores, P, softmax state, Q^T of blocks 0-1, addresses) stays with the compiler in v0..v255.
-// Hazards the compiler cannot see are padded inside the strings (MI355X guide 5.7: MFMA D -> VALU reader 12 states).
-// The audit after every edit: no compiler v_accvgpr_* and no scratch in the .s of this kernel.
-constexpr int W96_QB = 6;
-constexpr int W96_LDS_BYTES = (NST + NSTV) * TILE_BYTES + KRING * 256 + 64;
-constexpr int W96_Q0 = 192;
-
-template <int V>
-using ic = std::integral_constant<int, V>;
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (B < E) {
-        f(ic<B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-// acc[BASE..BASE+3] += A . B   (accumulator-file C/D, VGPR A and B)
-template <int BASE>
-__device__ __forceinline__ void mfma_acc(bf16x8 a, bf16x8 b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(BASE), "i"(BASE + 3));
-}
-// d = A . acc[QBASE..+3] + c   (VGPR C/D, B operand from the accumulator file); FIRST: d is a fresh register set
-template <int QBASE, bool FIRST, bool LAST>
-__device__ __forceinline__ void mfma_qacc(f32x4 &d, bf16x8 a) {
-    if constexpr (FIRST) {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(QBASE), "i"(QBASE + 3));
-    } else if constexpr (LAST) {   // the scores are read by VALU next: pad the MFMA D -> VALU hazard here
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %0\n\ts_nop 7\n\ts_nop 4" : "+v"(d) : "v"(a), "i"(QBASE), "i"(QBASE + 3));
-    } else {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QBASE), "i"(QBASE + 3));
-    }
-}
-// d = A . B (+ d), everything in VGPRs -- as an asm statement too: a builtin MFMA lets hipcc pick accumulator registers
-// for its C/D (it did: a0..a15, on top of O), and this kernel owns all of them
-template <bool FIRST>
-__device__ __forceinline__ void mfma_vv(f32x4 &d, bf16x8 a, bf16x8 b) {
-    if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-}
-template <int BASE>
-__device__ __forceinline__ f32x4 acc_read4() {
-    float x0, x1, x2, x3;
-    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"
-                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
-                 : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-    return (f32x4){x0, x1, x2, x3};
-}
-template <int BASE>
-__device__ __forceinline__ void acc_write4(f32x4 x) {
-    asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3\n\ts_nop 1"
-                 ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-}
-template <int BASE>
-__device__ __forceinline__ void acc_scale4(float f) {
-    float t;
-    asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0\n\t"
-                 "v_accvgpr_read_b32 %0, a%c3\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c3, %0\n\t"
-                 "v_accvgpr_read_b32 %0, a%c4\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c4, %0\n\t"
-                 "v_accvgpr_read_b32 %0, a%c5\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c5, %0"
-                 : "=&v"(t)
-                 : "v"(f), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-}
-
-template <bool GATHER, bool INPLACE, bool WRITE_L>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_w96_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Kl = smem;                      // [NST][TILE_BYTES]
-    unsigned char *Vl = smem + NST * TILE_BYTES;   // [NSTV][TILE_BYTES]
-    int *key_ring = (int *)(smem + (NST + NSTV) * TILE_BYTES);  // [KRING][64]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-
-    // the accumulator registers this kernel owns: zero O and the row sums (the clobber list also makes the kernel
-    // descriptor allocate the accumulator half of the register file)
-    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\tv_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\tv_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0\n\tv_accvgpr_write_b32 a128, 0\n\tv_accvgpr_write_b32 a129, 0\n\tv_accvgpr_write_b32 a130, 0\n\tv_accvgpr_write_b32 a131, 0\n\tv_accvgpr_write_b32 a132, 0\n\tv_accvgpr_write_b32 a133, 0\n\tv_accvgpr_write_b32 a134, 0\n\tv_accvgpr_write_b32 a135, 0\n\tv_accvgpr_write_b32 a136, 0\n\tv_accvgpr_write_b32 a137, 0\n\tv_accvgpr_write_b32 a138, 0\n\tv_accvgpr_write_b32 a139, 0\n\tv_accvgpr_write_b32 a140, 0\n\tv_accvgpr_write_b32 a141, 0\n\tv_accvgpr_write_b32 a142, 0\n\tv_accvgpr_write_b32 a143, 0\n\tv_accvgpr_write_b32 a144, 0\n\tv_accvgpr_write_b32 a145, 0\n\tv_accvgpr_write_b32 a146, 0\n\tv_accvgpr_write_b32 a147, 0\n\tv_accvgpr_write_b32 a148, 0\n\tv_accvgpr_write_b32 a149, 0\n\tv_accvgpr_write_b32 a150, 0\n\tv_accvgpr_write_b32 a151, 0\n\tv_accvgpr_write_b32 a152, 0\n\tv_accvgpr_write_b32 a153, 0\n\tv_accvgpr_write_b32 a154, 0\n\tv_accvgpr_write_b32 a155, 0\n\tv_accvgpr_write_b32 a156, 0\n\tv_accvgpr_write_b32 a157, 0\n\tv_accvgpr_write_b32 a158, 0\n\tv_accvgpr_write_b32 a159, 0\n\tv_accvgpr_write_b32 a160, 0\n\tv_accvgpr_write_b32 a161, 0\n\tv_accvgpr_write_b32 a162, 0\n\tv_accvgpr_write_b32 a163, 0\n\tv_accvgpr_write_b32 a164, 0\n\tv_accvgpr_write_b32 a165, 0\n\tv_accvgpr_write_b32 a166, 0\n\tv_accvgpr_write_b32 a167, 0\n\tv_accvgpr_write_b32 a168, 0\n\tv_accvgpr_write_b32 a169, 0\n\tv_accvgpr_write_b32 a170, 0\n\tv_accvgpr_write_b32 a171, 0\n\tv_accvgpr_write_b32 a172, 0\n\tv_accvgpr_write_b32 a173, 0\n\tv_accvgpr_write_b32 a174, 0\n\tv_accvgpr_write_b32 a175, 0\n\tv_accvgpr_write_b32 a176, 0\n\tv_accvgpr_write_b32 a177, 0\n\tv_accvgpr_write_b32 a178, 0\n\tv_accvgpr_write_b32 a179, 0\n\tv_accvgpr_write_b32 a180, 0\n\tv_accvgpr_write_b32 a181, 0\n\tv_accvgpr_write_b32 a182, 0\n\tv_accvgpr_write_b32 a183, 0\n\tv_accvgpr_write_b32 a184, 0\n\tv_accvgpr_write_b32 a185, 0\n\tv_accvgpr_write_b32 a186, 0\n\tv_accvgpr_write_b32 a187, 0\n\tv_accvgpr_write_b32 a188, 0\n\tv_accvgpr_write_b32 a189, 0\n\tv_accvgpr_write_b32 a190, 0\n\tv_accvgpr_write_b32 a191, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
-
-    const int wid0 = (int)blockIdx.x;
-    int sp = 0, nsp = 1, slot0 = 0, tix = 0, wid = wid0;
-    if (p.plan) {
-        wid = p.plan[2 * wid0];
-        if (wid < 0) return;
-        const int meta = p.plan[2 * wid0 + 1];
-        sp = meta & 0xffff, nsp = meta >> 16;
-        slot0 = tix = wid0 - sp;
-    } else if (p.nsplit > 1 && wid0 >= p.split_full) {
-        const int k = wid0 - p.split_full;
-        tix = k / p.nsplit;
-        sp = k - tix * p.nsplit;
-        nsp = p.nsplit;
-        slot0 = tix * p.nsplit;
-        wid = p.split_full + tix;
-    }
-    const int bh = wid / p.G, g = wid - bh * p.G;
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int count = GATHER ? p.counts[(int64_t)bh * p.G + g] : p.Nk;
-    const int valid = count < p.Nk ? count : p.Nk;
-    const int ntiles = (valid + KVT - 1) / KVT;
-    if (nsp > 1 && !p.plan) {
-        const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
-        nsp = nsp < cap ? nsp : cap;
-        if (sp >= nsp) return;
-    }
-    const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
-    const int32_t *idx = GATHER ? p.indices + ((int64_t)bh * p.G + g) * p.idx_stride : nullptr;
-    const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
-    const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
-    const int row0 = g * QG + w * (W96_QB * 16);
-    const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
-    const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;
-
-    // ---- Q^T fragments; query blocks 2..5 -> a[192:255]
-    auto load_q = [&](int qb, int ks) {
-        const int qrow = row0 + qb * 16 + li;
-        const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qrow * p.qs[2];
-        bf16x8 z = {};
-        return qrow < p.Nq ? *(const bf16x8 *)(qp + ks * 32 + lg * 8) : z;
-    };
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = load_q(qb, ks);
-    static_for<0, 16>([&](auto I) {
-        constexpr int qb = 2 + I.value / 4, ks = I.value % 4;
-        acc_write4<W96_Q0 + (qb - 2) * 16 + ks * 4>(__builtin_bit_cast(f32x4, load_q(qb, ks)));
-    });
-
-    auto issue_keys = [&](int T) {
-        if constexpr (GATHER) {
-            if (w == 0) {
-                int pos = T * KVT + lane;
-                pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T % KRING) * 64), 4, 0, 0);
-            }
-        }
-    };
-    // every wave stages rows (4w+i)*4 + lg, i = 0..3, of the K tile and of the V tile: 8 DMA instructions per wave and tile
-    auto issue_data = [&](int T) {
-        const int slot = T % NST;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (w * 4 + i) * 4 + lg;
-            const int pos = T * KVT + r;
-            int key = 0;
-            if (pos < valid) {
-                key = GATHER ? key_ring[(T % KRING) * 64 + r] : pos;
-                key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);
-            }
-            const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
-            const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
-            blds16(krsrc, koff, 0, Kl + slot * TILE_BYTES + (w * 4 + i) * 1024);
-            blds16(vrsrc, voff, 0, Vl + (T % NSTV) * TILE_BYTES + (w * 4 + i) * 1024);
-        }
-    };
-
-    f32x4 s[W96_QB][2];
-    bf16x8 pq[W96_QB];
-    float m[W96_QB], alpha[W96_QB], lsum[W96_QB];   // m: reference point of the exponentials, in exp2 units (scaled scores)
-#pragma unroll
-    for (int qb = 0; qb < W96_QB; ++qb) {
-        pq[qb] = (bf16x8){};
-        m[qb] = 0.f, alpha[qb] = 1.f, lsum[qb] = 0.f;
-    }
-
-    if (tend > tbeg) {
-#pragma unroll
-        for (int T = 0; T < NST - 1; ++T) issue_keys(tbeg + T);
-        wait_vmcnt<0>();
-        __syncthreads();
-#pragma unroll
-        for (int T = 0; T < NST - 1; ++T) {
-            if (tbeg + T < tend) {
-                issue_data(tbeg + T);
-                issue_keys(tbeg + T + NST - 1);
-            }
-        }
-    }
-
-    constexpr float MAX_LAG = 4.0f;                     // in exp2 units
-    constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;    // ... and in units of the raw scores
-    // m[]: reference point of the exponentials in RAW score units (p = exp2(s*c - m*c)), msc[] = m*c
-    float msc[W96_QB];
-#pragma unroll
-    for (int qb = 0; qb < W96_QB; ++qb) msc[qb] = 0.f;
-
-    auto wait_tile = [&](int t) {   // tile t has landed for everybody
-        if (t + NST - 1 <= tend) {
-            constexpr int L = 8;
-            if (GATHER && w == 0) wait_vmcnt<(NST - 2) * (L + 1)>();
-            else wait_vmcnt<(NST - 2) * L>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-    };
-    // one LDS-DMA piece pair (K rows and V rows 4*(4w+i) + lg of tile T): rides in a QK^T MFMA gap
-    auto issue_piece = [&](int T, int i) {
-        const int r = (w * 4 + i) * 4 + lg;
-        const int pos = T * KVT + r;
-        int key = 0;
-        if (pos < valid) {
-            key = GATHER ? key_ring[(T % KRING) * 64 + r] : pos;
-            key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);
-        }
-        const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
-        const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
-        blds16(krsrc, koff, 0, Kl + (T % NST) * TILE_BYTES + (w * 4 + i) * 1024);
-        blds16(vrsrc, voff, 0, Vl + (T % NSTV) * TILE_BYTES + (w * 4 + i) * 1024);
-    };
-    auto load_k = [&](const unsigned char *Kb, int i) {
-        const int kt = i >> 2, ks = i & 3;
-        const int pc = (ks * 4 + lg) ^ li;
-        return *(const bf16x8 *)(Kb + (kt * 16 + li) * 256 + pc * 16);
-    };
-    auto load_v = [&](const unsigned char *Vb, int db) {
-        const int row_a = lg * 4 + (li >> 2);
-        const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
-        const unsigned char *va = Vb + row_a * 256 + chunk * 16 + (li & 1) * 8;
-        const s16x4 lo = lds_read_tr16_b64(va);
-        const s16x4 hi = lds_read_tr16_b64(va + 16 * 256);
-        return __builtin_bit_cast(bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-    };
-    auto mask_tail = [&](f32x4 (&sx)[W96_QB][2], int t) {
-        if (t == ntiles - 1 && (valid & (KVT - 1)) != 0) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
-#pragma unroll
-                    for (int qb = 0; qb < W96_QB; ++qb) sx[qb][kt][r] = dead ? -INFINITY : sx[qb][kt][r];
-                }
-        }
-    };
-    auto raise_reference = [&](int qb, float m_new) {   // m_new >= m: move the reference point up
-        alpha[qb] = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
-        m[qb] = m_new;
-        msc[qb] = m_new * SCALE_LOG2E;
-        lsum[qb] *= alpha[qb];
-    };
-
-    // ---- phase 1 of iteration t: S(t) = K(t) . Q^T into `sn` (48 MFMAs) with, in the MFMA gaps, the tail of tile t-1's
-    //      softmax on `sc` (row sums, bf16 -> pq) and the LDS-DMA pieces of tile t+3.  `tail` / `dma`: do those parts.
-    auto qk_phase = [&](f32x4 (&sn)[W96_QB][2], f32x4 (&sc)[W96_QB][2], int t, bool tail, bool dma) {
-        const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
-        bf16x8 kr[3];
-        kr[0] = load_k(Kb, 0), kr[1] = load_k(Kb, 1);
-        static_for<0, 8>([&](auto I) {
-            constexpr int i = I.value, kt = i >> 2, ks = i & 3;
-            if constexpr (i + 2 < 8) kr[(i + 2) % 3] = load_k(Kb, i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, W96_QB>([&](auto Q) {
-                constexpr int qb = Q.value;
-                if constexpr (qb < 2) mfma_vv<ks == 0>(sn[qb][kt], kr[i % 3], qf[qb][ks]);
-                else mfma_qacc<W96_Q0 + (qb - 2) * 16 + ks * 4, ks == 0, ks == 3 && qb == W96_QB - 1>(sn[qb][kt], kr[i % 3]);
-                // gap work: group i < 6 finishes query block i of the previous tile: 8 adds + 4 converts over 6 gaps
-                if constexpr (i < W96_QB) {
-                    if (tail) {
-                        if constexpr (qb == 0) {
-                            pin(sc[i][0]);
-                            pin(sc[i][1]);
-                        }
-                        if constexpr (qb == 0) lsum[i] += sc[i][0][0] + sc[i][0][1];
-                        if constexpr (qb == 1) lsum[i] += sc[i][0][2] + sc[i][0][3];
-                        if constexpr (qb == 2) lsum[i] += sc[i][1][0] + sc[i][1][1];
-                        if constexpr (qb == 3) lsum[i] += sc[i][1][2] + sc[i][1][3];
-                        if constexpr (qb == 4) {
-                            bf16x8 pk = pq[i];
-                            pk[0] = (__bf16)sc[i][0][0], pk[1] = (__bf16)sc[i][0][1], pk[2] = (__bf16)sc[i][0][2], pk[3] = (__bf16)sc[i][0][3];
-                            pq[i] = pk;
-                        }
-                        if constexpr (qb == 5) {
-                            bf16x8 pk = pq[i];
-                            pk[4] = (__bf16)sc[i][1][0], pk[5] = (__bf16)sc[i][1][1], pk[6] = (__bf16)sc[i][1][2], pk[7] = (__bf16)sc[i][1][3];
-                            pq[i] = pk;
-                        }
-                        pin(lsum[i]);
-                        pin(pq[i]);
-                    }
-                }
-            });
-            if (dma) {
-                if constexpr (i < 4) issue_piece(t + NST - 1, i);
-                if constexpr (i == 4) issue_keys(t + 2 * (NST - 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        mask_tail(sn, t);
-    };
-    // ---- phase 2 of iteration t: O^T += V^T(t-1) . P^T(pq) (48 MFMAs) with, in the gaps, the head of tile t's softmax
-    //      on `sn`: in-lane max (d block 0), row max (1), [rare: reference update], exp2 of query block db-2 (2..7)
-    auto pv_phase = [&](f32x4 (&sn)[W96_QB][2], int tv, bool head) {
-        const unsigned char *Vb = Vl + (tv % NSTV) * TILE_BYTES;
-        bf16x8 vr[3];
-        float mx[W96_QB];
-        vr[0] = load_v(Vb, 0), vr[1] = load_v(Vb, 1);
-        static_for<0, 8>([&](auto DBc) {
-            constexpr int db = decltype(DBc)::value;
-            if constexpr (db + 2 < 8) vr[(db + 2) % 3] = load_v(Vb, db + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (db == 2) {
-                if (head) {   // every row maximum is known: does any query column of the wave outgrow the lag?
-                    bool quiet = true;
-#pragma unroll
-                    for (int qb = 0; qb < W96_QB; ++qb) quiet = quiet && (mx[qb] <= m[qb] + LAG_RAW);
-                    if (!__all(quiet)) {
-#pragma unroll
-                        for (int qb = 0; qb < W96_QB; ++qb) raise_reference(qb, fmaxf(m[qb], mx[qb]));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            static_for<0, W96_QB>([&](auto Q) {
-                constexpr int qb = Q.value;
-                mfma_acc<(qb * 8 + db) * 4>(vr[db % 3], pq[qb]);
-                if (head) {
-                    if constexpr (db == 0) {            // in-lane max of query block qb
-                        pin(sn[qb][0]);
-                        pin(sn[qb][1]);
-                        float x = max3(sn[qb][0][0], sn[qb][0][1], sn[qb][0][2]);
-                        x = max3(x, sn[qb][0][3], sn[qb][1][0]);
-                        x = max3(x, sn[qb][1][1], sn[qb][1][2]);
-                        mx[qb] = max2(x, sn[qb][1][3]);
-                        pin(mx[qb]);
-                    } else if constexpr (db == 1) {     // max across the 4 lane rows
-                        pin(mx[qb]);
-                        mx[qb] = max_rows(mx[qb]);
-                        pin(mx[qb]);
-                    } else {                            // exp2 of query block db-2: 8 scores over 6 gaps
-                        constexpr int e = db - 2;
-                        constexpr int lo = qb < 2 ? qb * 2 : qb + 2, hi = qb < 2 ? qb * 2 + 2 : qb + 3;
-                        if constexpr (qb == 0) {
-                            pin(sn[e][0]);
-                            pin(sn[e][1]);
-                        }
-#pragma unroll
-                        for (int j = lo; j < hi; ++j)
-                            sn[e][j >> 2][j & 3] = __builtin_amdgcn_exp2f(__builtin_fmaf(sn[e][j >> 2][j & 3], SCALE_LOG2E, -msc[e]));
-                        pin(sn[e][0]);
-                        pin(sn[e][1]);
-                    }
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    auto rescale_if_needed = [&]() {   // AFTER the pending PV has been accumulated (its MFMAs must have written back)
-        bool unit = true;
-#pragma unroll
-        for (int qb = 0; qb < W96_QB; ++qb) unit = unit && (alpha[qb] == 1.0f);
-        if (!__all(unit)) {
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-            static_for<0, W96_QB>([&](auto Q) {
-                constexpr int qb = Q.value;
-                static_for<0, 8>([&](auto DBc) { acc_scale4<(qb * 8 + decltype(DBc)::value) * 4>(alpha[qb]); });
-                alpha[qb] = 1.f;
-            });
-            asm volatile("s_nop 1" ::: "memory");
-        }
-    };
-
-    f32x4 sB[W96_QB][2];   // the second score buffer: S(t) is produced while P(t-1) is still being summed / converted
-    if (tend > tbeg) {
-        // ---- first tile: its own maximum becomes the reference point (exact), nothing to rescale
-        wait_tile(tbeg);
-        if (tbeg + NST - 1 < tend) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) issue_piece(tbeg + NST - 1, i);
-            issue_keys(tbeg + 2 * (NST - 1));
-        }
-        qk_phase(s, sB, tbeg, false, false);
-#pragma unroll
-        for (int qb = 0; qb < W96_QB; ++qb) {
-            float x = max3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
-            x = max3(x, s[qb][0][3], s[qb][1][0]);
-            x = max3(x, s[qb][1][1], s[qb][1][2]);
-            m[qb] = max_rows(max2(x, s[qb][1][3]));
-            m[qb] = m[qb] == -INFINITY ? 0.f : m[qb];
-            msc[qb] = m[qb] * SCALE_LOG2E;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[qb][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc[qb]));
-        }
-        // steady state, two tiles per trip so that the two score buffers keep their names
-        int t = tbeg + 1;
-        for (; t + 1 < tend; t += 2) {
-            wait_tile(t);
-            qk_phase(sB, s, t, true, t + NST - 1 < tend);
-            pv_phase(sB, t - 1, true);
-            rescale_if_needed();
-            wait_tile(t + 1);
-            qk_phase(s, sB, t + 1, true, t + NST < tend);
-            pv_phase(s, t, true);
-            rescale_if_needed();
-        }
-        if (t < tend) {   // one more tile: ends with P in sB
-            wait_tile(t);
-            qk_phase(sB, s, t, true, t + NST - 1 < tend);
-            pv_phase(sB, t - 1, true);
-            rescale_if_needed();
-#pragma unroll
-            for (int qb = 0; qb < W96_QB; ++qb) s[qb][0] = sB[qb][0], s[qb][1] = sB[qb][1];
-        }
-        // ---- drain: the last tile's row sums and bf16 P (in s), then its PV
-#pragma unroll
-        for (int qb = 0; qb < W96_QB; ++qb) {
-            lsum[qb] += (s[qb][0][0] + s[qb][0][1]) + (s[qb][0][2] + s[qb][0][3]);
-            lsum[qb] += (s[qb][1][0] + s[qb][1][1]) + (s[qb][1][2] + s[qb][1][3]);
-            bf16x8 pk;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pk[j] = (__bf16)s[qb][j >> 2][j & 3];
-            pq[qb] = pk;
-        }
-        pv_phase(s, tend - 1, false);
-    }
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last MFMAs' results before the accumulator file is read
-
-#pragma unroll
-    for (int qb = 0; qb < W96_QB; ++qb) lsum[qb] = sum_across_rows(lsum[qb]);   // the 4 lane rows hold 8 keys of every tile each
-
-    if (nsp > 1) {
-        // key-split item: same hand-off as attn_kernel; 52 float4 per thread x 128 threads = the same 104 KB slot
-        int *ticket_s = key_ring;
-        f32x4 *mine = (f32x4 *)p.ws + (int64_t)(slot0 + sp) * (26 * 256) + tid;
-        static_for<0, W96_QB * 8>([&](auto J) { mine[J.value * 128] = acc_read4<J.value * 4>(); });
-        mine[48 * 128] = (f32x4){m[0], m[1], m[2], m[3]};
-        mine[49 * 128] = (f32x4){m[4], m[5], 0.f, 0.f};
-        mine[50 * 128] = (f32x4){lsum[0], lsum[1], lsum[2], lsum[3]};
-        mine[51 * 128] = (f32x4){lsum[4], lsum[5], 0.f, 0.f};
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *ticket_s = __hip_atomic_fetch_add(p.tickets + tix, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (*ticket_s != nsp - 1) return;
-        if (tid == 0) {
-            __hip_atomic_store(p.tickets + tix, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-    // ---- epilogue, one query block at a time (32 accumulator registers pass through VGPRs): merge the slices of a
-    //      key-split item in slice order, then O = O^T / l
-    static_for<0, W96_QB>([&](auto Q) {
-        constexpr int qb = Q.value;
-        f32x4 ob[8];
-        float mq = m[qb], l = lsum[qb];
-        if (nsp > 1) {
-            mq = -INFINITY, l = 0.f;
-#pragma unroll
-            for (int db = 0; db < 8; ++db) ob[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int s2 = 0; s2 < nsp; ++s2) {
-                const f32x4 *oth = (const f32x4 *)p.ws + (int64_t)(slot0 + s2) * (26 * 256) + tid;
-                const float ms = oth[(48 + qb / 4) * 128][qb % 4], ls = oth[(50 + qb / 4) * 128][qb % 4];
-                if (ls == 0.f) continue;   // an empty slice (or a dead query column) carries no reference point
-                const float m_new = fmaxf(mq, ms);
-                const float a = __builtin_amdgcn_exp2f((mq - m_new) * SCALE_LOG2E), c = __builtin_amdgcn_exp2f((ms - m_new) * SCALE_LOG2E);
-                mq = m_new;
-                l = l * a + ls * c;
-#pragma unroll
-                for (int db = 0; db < 8; ++db) ob[db] = ob[db] * a + oth[(qb * 8 + db) * 128] * c;
-            }
-        } else {
-            static_for<0, 8>([&](auto DBc) { ob[decltype(DBc)::value] = acc_read4<(qb * 8 + decltype(DBc)::value) * 4>(); });
-        }
-        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
-        const int qrow = row0 + qb * 16 + li;
-        if (qrow < p.Nq) {
-            const int64_t ooff = b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + lg * 4;
-            uint16_t *op = p.o + ooff;
-            const uint16_t *oin = INPLACE ? p.o_in + ooff : nullptr;
-            if (INPLACE && ntiles == 0) {
-                if (oin != op) {
-#pragma unroll
-                    for (int db = 0; db < 8; ++db) *(u32x2 *)(op + db * 16) = *(const u32x2 *)(oin + db * 16);
-                }
-            } else {
-#pragma unroll
-                for (int db = 0; db < 8; ++db) {
-                    float x0 = ob[db][0] * inv, x1 = ob[db][1] * inv, x2 = ob[db][2] * inv, x3 = ob[db][3] * inv;
-                    u32x2 out;
-                    if constexpr (INPLACE) {
-                        const u32x2 old = *(const u32x2 *)(oin + db * 16);
-                        const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
-                        const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
-                        out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
-                        out[1] = pack_bf16x2(__uint_as_float(old[1] << 16) + a2, __uint_as_float(old[1] & 0xffff0000u) + a3);
-                    } else {
-                        out[0] = pack_bf16x2(x0, x1);
-                        out[1] = pack_bf16x2(x2, x3);
-                    }
-                    *(u32x2 *)(op + db * 16) = out;
-                }
-                if constexpr (WRITE_L) {
-                    if (lg == 0) p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(mq * SCALE_LOG2E) * l);
-                }
-            }
-        }
-    });
-}
-
 // Work plan for ragged key counts.  HunyuanVideo's text / tail query groups keep ALL 119k keys (13x a normal group); a
 // head-parallel rank launches only 3 heads (1 863 items on 512 slots), so one such item -- 6 ms on one workgroup -- would
 // be the whole launch.  One 1024-thread workgroup (a few microseconds) builds the plan on the device (the host never
@@ -1311,19 +786,6 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
                 pp.split_full = (int)(nblocks - rem);
                 grid = (nblocks - rem) + rem * f;
             }
-        }
-    }
-    if constexpr (!CSONLY) {
-        if (chipmunk_get_option("attn_w96") == 1) {
-            auto k96 = attn_w96_kernel<GATHER, INPLACE, WRITE_L>;
-            static bool w96_attr_set = false;
-            if (!w96_attr_set) {
-                (void)hipFuncSetAttribute((const void *)k96, hipFuncAttributeMaxDynamicSharedMemorySize, W96_LDS_BYTES);
-                w96_attr_set = true;
-            }
-            hipLaunchKernelGGL(k96, dim3((unsigned)grid), dim3(128), W96_LDS_BYTES, stream, pp);
-            CM_LAUNCH_CHECK();
-            return CHIPMUNK_OK;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, pp);
