@@ -216,28 +216,36 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             if (w == 0) {
                 int pos = T * KVT + lane;
                 pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T % KRING) * 64), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T & (KRING - 1)) * 64), 4, 0, 0);
             }
         }
     };
     // every wave stages rows (2w+i)*4 + lg, i = 0..1, of the K tile and of the V tile: 4 DMA instructions per wave
-    auto issue_data = [&](int T) {
-        const int slot = T % NST;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (w * 2 + i) * 4 + lg;  // row inside the tile
-            const int pos = T * KVT + r;
-            int key = 0;
-            if (pos < valid) {
-                key = GATHER ? key_ring[(T % KRING) * 64 + r] : pos;
-                key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);  // memory safety for malformed indices
-            }
-            // buffer-form DMA: per-(b, h) SGPR resource + 32-bit lane offset (row * stride + swizzled 16-byte chunk)
-            const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
-            const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
-            blds16(krsrc, koff, 0, Kl + slot * TILE_BYTES + (w * 2 + i) * 1024);
-            if constexpr (!CSONLY) blds16(vrsrc, voff, 0, Vl + (T % NSTV) * TILE_BYTES + (w * 2 + i) * 1024);
+    static_assert((NST & (NST - 1)) == 0 && (KRING & (KRING - 1)) == 0, "ring depths addressed by masks");
+    // the gather key of row (2w+i)*4 + lg of tile T, clamped into the key range (memory safety for malformed indices)
+    auto tile_key = [&](int T, int i) {
+        const int r = (w * 2 + i) * 4 + lg;
+        const int pos = T * KVT + r;
+        int key = 0;
+        if (pos < valid) {
+            key = GATHER ? key_ring[(T & (KRING - 1)) * 64 + r] : pos;
+            key = key < 0 ? 0 : (key >= p.Nk ? p.Nk - 1 : key);
         }
+        return key;
+    };
+    // buffer-form DMA of one K / V row pair per lane group: per-(b, h) SGPR resource + 32-bit lane offset (row * stride +
+    // swizzled 16-byte chunk); `vslot` = T mod NSTV, kept by the caller (5 is not a power of two)
+    auto issue_rows = [&](int T, int vslot, int i, int key) {
+        const int r = (w * 2 + i) * 4 + lg;
+        const uint32_t koff = ((uint32_t)key * kstride_b) + ((uint32_t)(li ^ (r & 15)) << 4);
+        const uint32_t voff = ((uint32_t)key * vstride_b) + ((uint32_t)(li ^ ((r & 7) << 1)) << 4);
+        blds16(krsrc, koff, 0, Kl + (T & (NST - 1)) * TILE_BYTES + (w * 2 + i) * 1024);
+        if constexpr (!CSONLY) blds16(vrsrc, voff, 0, Vl + vslot * TILE_BYTES + (w * 2 + i) * 1024);
+    };
+    auto issue_data = [&](int T) {   // prologue / column-sum pass form: keys read from the LDS key ring on the spot
+        const int vslot = (int)((unsigned)T % (unsigned)NSTV);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) issue_rows(T, vslot, i, tile_key(T, i));
     };
 
 
@@ -249,17 +257,18 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     float m[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lsum[3] = {0.f, 0.f, 0.f};
 
-    // ---- prologue: keys of tiles 0..NST-2 synchronously, then the data of those tiles (+ keys NST-1 .. 2NST-3)
+    // ---- prologue: keys of tiles 0..NST-1 synchronously, then the data of tiles 0..NST-2, each group followed by one more
+    //      key DMA (the main loop reads a tile's keys one iteration before it issues the tile's data: keys run 7 ahead)
     if (tend > tbeg) {
 #pragma unroll
-        for (int T = 0; T < NST - 1; ++T) issue_keys(tbeg + T);
+        for (int T = 0; T < NST; ++T) issue_keys(tbeg + T);
         wait_vmcnt<0>();
         __syncthreads();
 #pragma unroll
         for (int T = 0; T < (CSONLY ? 2 : NST - 1); ++T) {
             if (tbeg + T < tend) {
                 issue_data(tbeg + T);
-                issue_keys(tbeg + T + NST - 1);
+                issue_keys(tbeg + T + NST);
             }
         }
     }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         // S = Q . K^T with the MFMA operands swapped relative to the main loop: s[qb][kt][r] = score(q = qb*16 + lg*4 + r,
         // kv = kt*16 + li), so a lane owns one key and the sum over the wave's 48 queries is mostly in-lane
         auto cs_tile = [&](int t, int it) {
-            const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
+            const unsigned char *Kb = Kl + (t & (NST - 1)) * TILE_BYTES;
             f32x4 s[3][2];
             auto load_k = [&](int idx) {
                 const int kt = idx >> 2, ks = idx & 3;
@@ -348,6 +357,14 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         for (int qb = 0; qb < 3; ++qb) pq[qb] = (bf16x8){};
         f32x4 s[3][2];
         float alpha[3] = {1.f, 1.f, 1.f};
+        // keys of the tile whose data goes out NEXT, read from the key ring one iteration ahead (a read at the point of
+        // use costs two exposed LDS round trips per tile: ds_read -> lgkmcnt(0) -> address -> DMA, twice)
+        int knext[2] = {0, 0};
+        int v5 = (int)((unsigned)tbeg % (unsigned)NSTV);   // tbeg mod 5, advanced with t
+        if (tend > tbeg) {
+            knext[0] = tile_key(tbeg + NST - 1, 0);
+            knext[1] = tile_key(tbeg + NST - 1, 1);
+        }
         auto tile_sync = [&](int t) {   // tile t has landed for everybody; the DMA of tile t+3 goes out
             if (t + NST - 1 <= tend) {
                 constexpr int L = 4;
@@ -359,13 +376,17 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             __builtin_amdgcn_s_barrier();
             PROF_MARK(0);
             if (t + NST - 1 < tend) {
-                issue_data(t + NST - 1);
-                issue_keys(t + 2 * (NST - 1));
+                const int vs = v5 + NST - 1 >= NSTV ? v5 + NST - 1 - NSTV : v5 + NST - 1;   // (t + 3) mod 5
+                issue_rows(t + NST - 1, vs, 0, knext[0]);
+                issue_rows(t + NST - 1, vs, 1, knext[1]);
+                issue_keys(t + 2 * (NST - 1) + 1);
+                knext[0] = tile_key(t + NST, 0);   // landed: issued 3 iterations ago, this iteration's wait covers it
+                knext[1] = tile_key(t + NST, 1);
             }
             PROF_MARK(1);
         };
         auto qk_tile = [&](int t) {     // S^T(t) = K(t) . Q^T, dead keys of a ragged last tile masked
-            const unsigned char *Kb = Kl + (t % NST) * TILE_BYTES;
+            const unsigned char *Kb = Kl + (t & (NST - 1)) * TILE_BYTES;
             auto load_k = [&](int i) {
                 const int kt = i >> 2, ks = i & 3;
                 const int pc = (ks * 4 + lg) ^ li;
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             return pk;
         };
         auto pv_mfmas = [&](int tv) {   // O^T += V^T(tv) . P^T(pq): 16 transpose reads + 24 MFMAs
-            const unsigned char *Vb = Vl + (tv % NSTV) * TILE_BYTES;
+            const unsigned char *Vb = Vl + (int)((unsigned)tv % (unsigned)NSTV) * TILE_BYTES;
 #pragma unroll
             for (int db = 0; db < 8; ++db) {
                 const int row_a = lg * 4 + (li >> 2);
@@ -451,6 +472,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
             PROF_MARK(3);
             for (int t = tbeg + 1; t < tend; ++t) {
+                v5 = v5 + 1 == NSTV ? 0 : v5 + 1;   // t mod 5
                 tile_sync(t);
                 qk_tile(t);
                 // ---- PV of tile t-1 and the softmax of tile t, hand-interleaved: 8 chunks, each = 3 MFMAs (one 16-wide d
@@ -458,7 +480,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 // stay in the shadow of MFMAs that do not depend on them (left to itself hipcc runs the whole softmax first
                 // and the MFMAs after it; sched_group_barrier requests did not move it).
                 {
-                    const unsigned char *Vb = Vl + ((t - 1) % NSTV) * TILE_BYTES;
+                    const unsigned char *Vb = Vl + (v5 == 0 ? NSTV - 1 : v5 - 1) * TILE_BYTES;   // (t - 1) mod 5
                     auto load_v = [&](int db) {
                         const int row_a = lg * 4 + (li >> 2);
                         const int chunk = (db * 2 + ((li & 3) >> 1)) ^ ((row_a & 7) << 1);
