@@ -425,11 +425,12 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             x = max3(x, s[qb][1][1], s[qb][1][2]);
             return max2(x, s[qb][1][3]);
         };
-        auto exp_block = [&](int qb, float msc) {   // p = exp2(s*c - m*c), in place
+        float nmsc[3] = {0.f, 0.f, 0.f};            // -m*c, kept beside m (recomputed only when the reference point moves)
+        auto exp_block = [&](int qb, float nm) {    // p = exp2(s*c - m*c), in place
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[qb][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, -msc));
+                for (int r = 0; r < 4; ++r) s[qb][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], SCALE_LOG2E, nm));
         };
         auto row_sum = [&](int qb) {    // l += sum of the 8 p a lane holds (in place of s)
             float x = (s[qb][0][0] + s[qb][0][1]) + (s[qb][0][2] + s[qb][0][3]);
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 #pragma unroll
             for (int qb = 0; qb < 3; ++qb) {
                 m[qb] = max_rows(tile_max(qb));
-                exp_block(qb, m[qb] * SCALE_LOG2E);
+                nmsc[qb] = -m[qb] * SCALE_LOG2E;
+                exp_block(qb, nmsc[qb]);
                 row_sum(qb);
                 pq[qb] = to_bf16(qb);
             }
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 v5 = v5 + 1 == NSTV ? 0 : v5 + 1;   // t mod 5
                 tile_sync(t);
                 qk_tile(t);
+                bool moved = false;   // wave-uniform: the reference point moved in this tile
                 // ---- PV of tile t-1 and the softmax of tile t, hand-interleaved: 8 chunks, each = 3 MFMAs (one 16-wide d
                 // block) + the V^T fragment of the block two ahead + one slice of the softmax, fenced so that the slices
                 // stay in the shadow of MFMAs that do not depend on them (left to itself hipcc runs the whole softmax first
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                     };
                     bf16x8 vr[3];
                     vr[0] = load_v(0), vr[1] = load_v(1);
-                    float mx[3], msc[3];
+                    float mx[3];
                     __builtin_amdgcn_sched_barrier(0);
                     // chunks 0, 1: maxima; then the (rare) reference update in its own block; chunks 2..7: exp2, row sums
 #pragma unroll
@@ -517,16 +520,16 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                     }
                     constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;   // the lag in units of the raw scores
                     if (!__all(mx[0] <= m[0] + LAG_RAW && mx[1] <= m[1] + LAG_RAW && mx[2] <= m[2] + LAG_RAW)) {
+                        moved = true;
 #pragma unroll
                         for (int qb = 0; qb < 3; ++qb) {
                             const float m_new = max2(m[qb], mx[qb]);
                             alpha[qb] = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
                             lsum[qb] *= alpha[qb];   // (o is rescaled once the pending PV has been accumulated)
                             m[qb] = m_new;
+                            nmsc[qb] = -m_new * SCALE_LOG2E;
                         }
                     }
-#pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) msc[qb] = m[qb] * SCALE_LOG2E;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int db = 2; db < 8; ++db) {
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                         for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
                         if (db <= 4) {              // exp2 of one query block per chunk
                             const int qb = db - 2;
-                            exp_block(qb, msc[qb]);
+                            exp_block(qb, nmsc[qb]);
                             pin(s[qb][0]);
                             pin(s[qb][1]);
                         } else {                    // row sums
@@ -552,12 +555,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 }
                 PROF_MARK(3);
                 // rescale AFTER the pending PV has been accumulated: O_t = alpha_t (O_{t-1} + P_{t-1} V_{t-1}) + P_t V_t
-                if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f && alpha[2] == 1.0f)) {
+                if (moved) {
 #pragma unroll
                     for (int qb = 0; qb < 3; ++qb) {
 #pragma unroll
                         for (int db = 0; db < 8; ++db) o[qb][db] *= alpha[qb];
-                        alpha[qb] = 1.f;
                     }
                 }
                 PROF_MARK(4);
