@@ -817,6 +817,13 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     return CHIPMUNK_OK;
 }
 
+// one-wave-per-SIMD kernel for long dense launches (attn64.hip); option attn_dense64: 0 = by size, 1 = always, 2 = never
+bool use_dense64(int B, int H, int Nq, int Nk) {
+    const int o = chipmunk_get_option("attn_dense64");
+    if (o) return o == 1 && Nk >= 64;
+    return (int64_t)B * H * ((Nq + 255) / 256) >= 3 * (int64_t)device_cu_count() && Nk >= 2048;
+}
+
 int check_common(const void *q, const void *k, const void *v, const void *o, int B, int H, int Nq, int Nk) {
     CM_CHECK(q && k && v && o, "attention: null tensor pointer");
     CM_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: B,H,Nq,Nk must be positive (got %d,%d,%d,%d)", B, H, Nq, Nk);
@@ -912,6 +919,11 @@ extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, 
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
+    if (use_dense64(B, H, Nq, Nk)) {
+        CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
+                 "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
+        return chipmunk_dense64_launch(q, k, v, o, l, p.qs, p.ks, p.vs, p.os, B, H, Nq, Nk, (hipStream_t)stream);
+    }
     return launch_attn<false, false, true>(p, (hipStream_t)stream);
 }
 
@@ -936,6 +948,13 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     // share nothing but their inputs.  (A single fused pass was built first: it sat on the 256-VGPR cliff and measured
     // 885 vs 480 us at FLUX size, 36.9 vs 23.5 ms for two HunyuanVideo heads; removed.)
     hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_attn<false, false, true>(p, st);
+    int rc;
+    if (use_dense64(B, H, Nq, Nk)) {
+        CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
+                 "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
+        rc = chipmunk_dense64_launch(q, k, v, o, l, p.qs, p.ks, p.vs, p.os, B, H, Nq, Nk, st);
+    } else {
+        rc = launch_attn<false, false, true>(p, st);
+    }
     return rc != CHIPMUNK_OK ? rc : launch_attn<false, false, false, true>(p, st);
 }

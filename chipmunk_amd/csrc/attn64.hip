@@ -1,0 +1,451 @@
+// Dense attention for long sequences on gfx950: ONE wave per SIMD, 64 query rows per wave, v_mfma_f32_32x32x16_bf16.
+//
+// The general kernel (attn.hip) runs two 4-wave workgroups per CU with 48 rows per wave on 16x16x32 MFMAs; its loop is
+// bound by the issue slots the two waves of a SIMD share.  This kernel is the other point of the design
+// space, for the dense launches of HunyuanVideo / Wan size (reference csrc/attn/dense_attn.cu:246-372):
+//   * workgroup = 256 query rows = 4 waves x 64 rows, one workgroup per CU, every wave owns the whole 512-entry
+//     register file of its SIMD: O^T (64 x 128 f32) in a[0:127], Q^T fragments in a[128:191], the K fragments of the
+//     current tile in a[192:255] -- all three only ever touched by inline asm -- and the softmax in the 256 VGPRs;
+//   * 64-key tiles; S^T = K.Q^T (swapped operands): a lane owns one query column (lane & 31) and 16 of the 32 keys of a
+//     block, so the running maximum / sum are lane-local and the bf16 P^T feeds O^T += V^T.P^T without any cross-lane
+//     movement (the k-order permutation is absorbed by the order of the V^T transpose reads);
+//   * per tile two phases of 32 MFMAs (32 cycles each: 8 issue slots, of which the fillers may take ~5):
+//       A(t): S(t) = K(t).Q^T     beside  exp2 / row sums / bf16 packing of tile t-1
+//       B(t): O += V(t-1).P(t-1)  beside  the maxima and s*c - m*c of tile t, the K(t+1) fragment reads, V reads;
+//   * K/V tiles by LDS-DMA into 4-slot rings (K four tiles ahead, V two), one s_barrier and one counted vmcnt per tile;
+//   * the reference point of the exponentials lags the running maximum by <= 2^4 (as in attn.hip): the rescale of the
+//     128 accumulator registers runs a handful of times per item.
+// The loop is unrolled over the four ring slots so that every LDS address is base + immediate.
+#include "common.h"
+#include "attn64_regs.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int KT = 64;                    // keys per tile
+constexpr int WROWS = 64, WGROWS = 256;   // query rows per wave / workgroup
+constexpr int TB = KT * HD * 2;           // 16 KiB per K or V tile
+constexpr int NSL = 4;                    // ring slots, K and V each
+constexpr int VRING = NSL * TB;           // byte offset of the V ring
+constexpr int LDS_BYTES = 2 * NSL * TB;   // 128 KiB
+constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
+constexpr float MAX_LAG = 4.0f;
+// timing ablations (tools/attn64_ablate.py builds one library per value; results are wrong, only the clock is read):
+// 1 = no exp2 / row sums / packing, 2 = no maxima / s*c - m*c, 4 = no V^T reads, 8 = no K reads, 16 = no DMA, barrier, vmcnt
+#ifndef A64_ABL
+#define A64_ABL 0
+#endif
+
+#ifdef ATTN64_PROF
+// cycle anatomy (tools/attn64_prof.py builds a separate library with -DATTN64_PROF): s_memtime at the segment boundaries
+// of every tile, summed per segment, for every wave of one mid-grid workgroup.  Not part of the product build.
+__device__ unsigned long long g_a64_prof[4 * 8];
+#define P64_DECL unsigned long long pt_ = 0, pacc_[7] = {0, 0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == (gridDim.x / 2)
+#define P64_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define P64_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define P64_END(w, n) do { if (prof_on_ && lane == 0) { for (int i_ = 0; i_ < 7; ++i_) g_a64_prof[(w) * 8 + i_] = pacc_[i_]; g_a64_prof[(w) * 8 + 7] = (n); } } while (0)
+#else
+#define P64_DECL
+#define P64_START()
+#define P64_MARK(i)
+#define P64_END(w, n)
+#endif
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(ic<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pin(T &x) {
+    asm volatile("" : "+v"(x));
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// S^T block (kb, qb) (+)= K fragment (kb, ks) . Q^T fragment (qb, ks); both operands live in the accumulator file
+template <int KB, int QB, int KS>
+__device__ __forceinline__ void mfma_qk(f32x16 &s) {
+    constexpr int ka = 192 + (KB * 8 + KS) * 4, qa = 128 + (QB * 8 + KS) * 4;
+    if constexpr (KS == 0)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
+}
+// O^T block (qb, db) += V^T fragment . P^T fragment
+template <int QB, int DB>
+__device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &pf) {
+    constexpr int oa = (QB * 4 + DB) * 16;
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(oa), "i"(oa + 15));
+}
+// K fragment (kb, ks) of the tile in ring slot SLOT -> a[192 + ...]; completion is counted by the caller (lgkmcnt)
+template <int KB, int KS, int SLOT>
+__device__ __forceinline__ void lds_k(uint32_t addr) {
+    constexpr int ka = 192 + (KB * 8 + KS) * 4;
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(ka), "i"(ka + 3), "i"(SLOT * TB + KB * 8192) : "memory");
+}
+template <int BASE>
+__device__ __forceinline__ void acc_write4(const u32x4 &v) {
+    asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3\n\ts_nop 1"
+                 ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+}
+template <int BASE>
+__device__ __forceinline__ f32x4 acc_read4() {
+    float a, b, c, d;
+    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"
+                 : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+    return (f32x4){a, b, c, d};
+}
+
+struct D64Params {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    int64_t qs[3], ks[3], vs[3], os[3];
+    float *l_out;
+    int B, H, Nq, Nk, G;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense64_kernel(const D64Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5, l15 = lane & 15, lg = lane >> 4;
+    const int wid = blockIdx.x;
+    const int bh = wid / p.G, g = wid - bh * p.G;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int row0 = g * WGROWS + w * WROWS;
+    const int ntiles = (p.Nk + KT - 1) / KT;
+    const int T4 = (ntiles + 3) & ~3;
+
+    const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
+    const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
+    const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
+    const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;
+
+    // ---- accumulator file: O^T = 0, Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7)
+    asm volatile(A64_ZERO_O ::: A64_CLOBBER_ALL);
+    {
+        const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1];
+        static_for<0, 16>([&](auto f) {
+            constexpr int F = decltype(f)::value, qb = F >> 3, ks = F & 7;
+            const int qrow = row0 + qb * 32 + l31;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
+            acc_write4<128 + F * 4>(val);
+        });
+    }
+
+    // ---- lane-constant LDS addresses.  K tile: row-major [64][256 B], 16-byte chunk c of row r stored at c ^ (r & 15);
+    //      V tile: chunk c of row r stored at c ^ ((r & 3) << 2).  Both swizzles are applied on the DMA source side.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    uint32_t kad[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kad[ks] = lds0 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4);
+    uint32_t vad[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+        vad[db] = lds0 + VRING + (4 * hf + (l15 >> 2)) * 256 + (((db * 4 + 2 * (lg & 1) + ((l15 & 3) >> 1)) ^ ((l15 >> 2) << 2)) << 4) +
+                  (l15 & 1) * 8;
+    // DMA: wave w stages pieces w*4 + i (4 rows of 256 B each), i = 0..3, of the K tile and of the V tile
+    uint32_t kofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kofs[i] = (uint32_t)(w * 16 + 4 * i + lg) * kstride_b + ((uint32_t)(l15 ^ (4 * i + lg)) << 4);
+    const uint32_t vofs = (uint32_t)(w * 16 + lg) * vstride_b + ((uint32_t)(l15 ^ (lg << 2)) << 4);
+
+    // One DMA piece (4 rows) of tile T.  A ragged last tile and the padding tiles are fetched from the last 64 rows of
+    // the key range instead (rows [Nk-64, Nk): in bounds, wave-uniform), which shifts the tile's live keys to the END of
+    // its LDS rows; the dead rows in front hold keys of the previous tile and are masked in the scores.
+    const int last_base = p.Nk - KT;
+    auto tile_base = [&](int T) { return T * KT < last_base ? T * KT : last_base; };
+    auto issue_k1 = [&](uint32_t soff, uint32_t ldsw, int slot, int i) {
+        blds16(krsrc, kofs[i], soff, smem + ldsw + slot * TB + i * 1024);
+    };
+    auto issue_v1 = [&](uint32_t soff, uint32_t ldsw, int slot, int i) {
+        blds16(vrsrc, vofs, soff + (uint32_t)(4 * i) * vstride_b, smem + ldsw + VRING + slot * TB + i * 1024);
+    };
+    auto issue_k = [&](int T, int slot) {
+        const uint32_t soff = (uint32_t)tile_base(T) * kstride_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_k1(soff, w * 4096, slot, i);
+    };
+    auto issue_v = [&](int T, int slot) {
+        const uint32_t soff = (uint32_t)tile_base(T) * vstride_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_v1(soff, w * 4096, slot, i);
+    };
+
+    // ---- prologue: K(0), then the issues of "iterations" -3..-1 (iteration i issues K(i+4) and V(i+2); V(-1) does not
+    //      exist: V(0) goes into its slot so that the first tile's PV -- P = 0 -- multiplies finite numbers)
+    issue_k(0, 0);
+    issue_k(1, 1), issue_v(0, 3);
+    issue_k(2, 2), issue_v(0, 0);
+    issue_k(3, 3), issue_v(1, 1);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __syncthreads();
+    static_for<0, 16>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        lds_k<(I >> 3), (I & 7), 0>(kad[I & 7]);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    f32x16 s[4];        // S^T(t), block kb*2 + qb
+    float px[64];       // x = s*c - m*c, then p = exp2(x), of the tile being finished; e = blk*16 + r
+    uint32_t pw[2][4][4] = {};   // P^T fragments (qb, key slab u', dword); zero: the first tile's PV multiplies P(-1) = 0
+    float m[2] = {-INFINITY, -INFINITY}, nmsc[2] = {0.f, 0.f};
+    float lacc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float alpha[2] = {1.f, 1.f};
+    // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
+#pragma unroll
+    for (int e = 0; e < 64; ++e) px[e] = e < 20 ? 0.f : -INFINITY;
+
+    // V^T fragment: keys {4hf + 0..3, 8 + 4hf + 0..3} of a 16-key slab, d = db*32 + l31.  Issued through asm: hipcc puts a
+    // vmcnt(0) in front of every LDS read it knows about while an LDS-DMA is in flight (it cannot tell the slots apart),
+    // which here would wait for the tiles just requested.  The caller waits (lgkmcnt) before the first use.
+    auto vfrag_read = [&](auto dbc, auto offc) __attribute__((always_inline)) {
+        constexpr int DB = decltype(dbc)::value, OFF = decltype(offc)::value;
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
+                     : "=v"(lo), "=v"(hi) : "v"(vad[DB]), "i"(OFF), "i"(OFF + 2048) : "memory");
+        return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    };
+
+    // ---- the softmax of a tile as a pipeline of single-instruction stages over its 64 scores per lane, in SEQUENCE order
+    //      i = kb*32 + u*16 + qb*8 + rr  (element r = 8u + rr of block kb*2 + qb): key slab u' = kb*2 + u is complete after
+    //      every 16 elements, which is the order the PV MFMAs consume the P^T fragments in.
+    //        X_i: px[i] = s*c - m*c          phase B(t), gaps 12..27, four per gap
+    //        E_i: px[i] = exp2(px[i])        v_exp_f32 runs at a quarter of the VALU rate: 64 of them are half of a tile's
+    //                                        VALU time, so they are spread one per gap over B(t) 12..31 (step k = 0..19),
+    //                                        A(t+1) (k = 20..51, five per four gaps) and B(t+1) 0..3 (k = 52..55)
+    //        L_i: row sum, one step behind E;  C_j: bf16 pair j = (2j, 2j+1), one step behind E of its second element.
+    //      Slab deadlines (first PV MFMA that reads the fragment): slab 0 at B(t+1) gap 0 (packed by k = 17), slab 1 at gap 8
+    //      (k = 31), slab 2 at gap 16 (k = 44), slab 3 at gap 24 (k = 57 = gap 5).
+    auto ecum = [](int k) constexpr { return k <= 0 ? 0 : k <= 20 ? k : k <= 52 ? 20 + (k - 20) + ((k - 20) >> 2) : (k <= 56 ? 8 + k : 64); };
+    auto finish_step = [&](auto kk) __attribute__((always_inline)) {
+        constexpr int K = decltype(kk)::value;
+        if constexpr (!(A64_ABL & 1)) {
+            static_for<ecum(K), ecum(K + 1)>([&](auto ii) {           // E
+                constexpr int I = decltype(ii)::value;
+                px[I] = __builtin_amdgcn_exp2f(px[I]);
+                pin(px[I]);
+            });
+            static_for<ecum(K - 1), ecum(K)>([&](auto ii) {           // L
+                constexpr int I = decltype(ii)::value;
+                lacc[(I >> 3) & 1][I & 1] += px[I];
+                pin(lacc[(I >> 3) & 1][I & 1]);
+            });
+            static_for<(ecum(K - 1) >> 1), (ecum(K) >> 1)>([&](auto jj) {   // C
+                constexpr int J = decltype(jj)::value, I = 2 * J;
+                pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1] = pack_bf16x2(px[I], px[I + 1]);
+                pin(pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1]);
+            });
+        }
+    };
+
+    P64_DECL;
+    P64_START();
+    // one tile: ring slot SL = t mod 4 (static), K(t) already in a[192:255]
+    auto tile = [&](auto slc, int t) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slc)::value;
+        constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
+        constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
+        // K(t+1) and V(t-1) were issued three iterations ago: the issues of the last two iterations may stay in flight
+        uint32_t ldsw = w * 4096, ksoff = 0, vsoff = 0;
+        if constexpr (!(A64_ABL & 16)) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (opaque copies: the 32 destination addresses of the four unrolled tiles are sums the loop recomputes with one
+            // SALU op each instead of values the compiler hoists and then spills)
+            asm volatile("" : "+s"(ldsw));
+            ksoff = (uint32_t)tile_base(t + 4) * kstride_b;
+            vsoff = (uint32_t)tile_base(t + 2) * vstride_b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        P64_MARK(0);
+
+        u32x4 vf[16];
+        // ================= phase A: S(t) = K(t).Q^T  ||  tile t-1: steps 20..51 of its softmax pipeline =================
+        static_for<0, 32>([&](auto gg) {
+            constexpr int G = decltype(gg)::value;
+            constexpr int ks = G >> 2, kb = (G >> 1) & 1, qb = G & 1;
+            mfma_qk<kb, qb, ks>(s[kb * 2 + qb]);
+            if constexpr (G < 8 && !(A64_ABL & 16)) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2): one piece per gap
+                if constexpr (G < 4) issue_k1(ksoff, ldsw, SL, G);
+                else issue_v1(vsoff, ldsw, (SL + 2) & 3, G - 4);
+            }
+            finish_step(ic<20 + G>{});
+            if constexpr (G < 16) {   // all sixteen V^T fragments of tile t-1, one per gap: the LDS pipe carries V in phase A and K in
+                constexpr int f = G;  // phase B (each wave reads both tiles whole: 2 x 64 KiB per CU and tile = 1024 LDS cycles)
+                if constexpr (A64_ABL & 4) vf[f] = (u32x4){(uint32_t)t, 1u, 2u, 3u};
+                else vf[f] = vfrag_read(ic<(f & 3)>{}, ic<VSL * TB + (f >> 2) * 4096>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        P64_MARK(1);
+        // the sixteen fragments have landed (the statement names them: nothing that reads one is scheduled above it)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vf[4]), "+v"(vf[5]), "+v"(vf[6]), "+v"(vf[7]), "+v"(vf[8]),
+                       "+v"(vf[9]), "+v"(vf[10]), "+v"(vf[11]), "+v"(vf[12]), "+v"(vf[13]), "+v"(vf[14]), "+v"(vf[15]));
+        __builtin_amdgcn_sched_barrier(0);
+        P64_MARK(2);
+
+        // ======= phase B: O += V(t-1).P(t-1)  ||  tile t-1: steps 52..57; tile t: maxima, X, steps 0..19; K(t+1) -> a[192:255] ====
+        float mx[2];
+        bool moved = false;
+        const int dead = t * KT - tile_base(t) < KT ? t * KT - tile_base(t) : KT;   // see tile_base: 0 for every full tile
+        auto phase_b_gap = [&](auto gg) __attribute__((always_inline)) {
+            constexpr int G = decltype(gg)::value;
+            constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
+            const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
+            mfma_pv<qb, db>(vf[G >> 1], pf);
+            if constexpr (G < 6) finish_step(ic<52 + G>{});
+            if constexpr ((G & 1) == 0 && !(A64_ABL & 8)) {    // K(t+1) fragments, one every other gap (nothing in this phase waits on LDS)
+                constexpr int J = G >> 1;
+                lds_k<(J >> 3), (J & 7), KNSL>(kad[J & 7]);
+            }
+            if constexpr (G == 1 && !(A64_ABL & 2)) {   // ragged / padding tile: its first `dead` LDS rows are not this tile's keys
+                if (dead > 0) {                         // (wave-uniform, last tiles only)
+                    int thr = dead - 4 * hf;            // opaque: the 32 per-register row numbers are compared as immediates
+                    asm volatile("" : "+v"(thr));
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((blk >> 1) * 32 + (r & 3) + 8 * (r >> 2) < thr) s[blk][r] = -INFINITY;
+                }
+            }
+            if constexpr (G >= 2 && G <= 9 && !(A64_ABL & 2)) {   // maxima of the 32 scores a lane holds per query block: 16 x v_max3 each, two per
+                constexpr int j = G - 2;        // block per gap, the four of a gap in one statement (one boundary pad, not four)
+                constexpr int kb2 = j >> 2, r0 = (j & 3) * 4;
+                if constexpr (j == 0) mx[0] = mx[1] = -INFINITY;
+                asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
+                             : "+v"(mx[0]), "+v"(mx[1])
+                             : "v"(s[kb2 * 2][r0]), "v"(s[kb2 * 2][r0 + 1]), "v"(s[kb2 * 2][r0 + 2]), "v"(s[kb2 * 2][r0 + 3]),
+                               "v"(s[kb2 * 2 + 1][r0]), "v"(s[kb2 * 2 + 1][r0 + 1]), "v"(s[kb2 * 2 + 1][r0 + 2]), "v"(s[kb2 * 2 + 1][r0 + 3]));
+            }
+            if constexpr (G == 10 && !(A64_ABL & 2)) {  // the other half of the keys lives in lane ^ 32
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    float a = mx[q2], c = mx[q2];
+                    lane_swap32(a, c);
+                    mx[q2] = max2(a, c);
+                    pin(mx[q2]);
+                }
+            }
+            if constexpr (G >= 12 && G < 28 && !(A64_ABL & 2)) {   // X: four elements per gap, sequence order
+                static_for<(G - 12) * 4, (G - 11) * 4>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    constexpr int blk = (I >> 5) * 2 + ((I >> 3) & 1), r = ((I >> 4) & 1) * 8 + (I & 7);
+                    px[I] = __builtin_fmaf(s[blk][r], SCALE_LOG2E, nmsc[(I >> 3) & 1]);
+                    pin(px[I]);
+                });
+            }
+            if constexpr (G >= 12) finish_step(ic<G - 12>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_for<0, 12>(phase_b_gap);
+        P64_MARK(3);
+        if constexpr (!(A64_ABL & 2)) {   // the (rare) move of the reference point
+            constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
+            if (!__all(mx[0] <= m[0] + LAG_RAW && mx[1] <= m[1] + LAG_RAW)) {
+                moved = true;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const float m_new = max2(m[q2], mx[q2]);
+                    alpha[q2] = __builtin_amdgcn_exp2f((m[q2] - m_new) * SCALE_LOG2E);
+                    lacc[q2][0] *= alpha[q2];
+                    lacc[q2][1] *= alpha[q2];
+                    m[q2] = m_new;
+                    nmsc[q2] = -m_new * SCALE_LOG2E;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        P64_MARK(4);
+        static_for<12, 32>(phase_b_gap);
+        P64_MARK(5);
+        if (moved) {   // O_t = alpha (O_{t-1} + P_{t-1} V_{t-1}): after the pending PV, before the next one
+            float tmp;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A64_SCALE_QB0 : "=&v"(tmp) : "v"(alpha[0]));
+            asm volatile(A64_SCALE_QB1 : "=&v"(tmp) : "v"(alpha[1]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K(t+1) fragments have landed
+        __builtin_amdgcn_sched_barrier(0);
+        P64_MARK(6);
+    };
+
+    // tiles 0 .. T4-1 (multiples of four: the padding tiles are fully masked), then one more pass whose phase A finishes
+    // tile T4-1 and whose phase B accumulates it (its own -- masked -- tile is never finished)
+    for (int tb = 0;; tb += 4) {
+        tile(ic<0>{}, tb);
+        if (tb >= T4) break;
+        tile(ic<1>{}, tb + 1);
+        tile(ic<2>{}, tb + 2);
+        tile(ic<3>{}, tb + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P64_END(w, T4 + 1);
+
+    // ---- epilogue: O = O^T / l; a lane holds, per (qb, db), four groups of 4 consecutive d of query row qb*32 + l31
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    static_for<0, 2>([&](auto qq) {
+        constexpr int QB = decltype(qq)::value;
+        float lp = lacc[QB][0] + lacc[QB][1], lo2 = lp;
+        lane_swap32(lp, lo2);
+        const float l = lp + lo2;
+        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
+        const int qrow = row0 + QB * 32 + l31;
+        uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + 4 * hf;
+        static_for<0, 16>([&](auto ii) {
+            constexpr int I = decltype(ii)::value, DB = I >> 2, R4 = I & 3;
+            const f32x4 o4 = acc_read4<(QB * 4 + DB) * 16 + R4 * 4>();
+            u32x2 out;
+            out[0] = pack_bf16x2(o4[0] * inv, o4[1] * inv);
+            out[1] = pack_bf16x2(o4[2] * inv, o4[3] * inv);
+            if (qrow < p.Nq) *(u32x2 *)(op + DB * 32 + R4 * 8) = out;
+        });
+        if (p.l_out && hf == 0 && qrow < p.Nq)
+            p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[QB] * SCALE_LOG2E) * l);
+    });
+}
+
+}  // namespace
+
+#ifdef ATTN64_PROF
+extern "C" int chipmunk_attn64_prof_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a64_prof), sizeof(g_a64_prof)) == hipSuccess ? 0 : 2;
+}
+#endif
+
+// dense attention through the one-wave-per-SIMD kernel; returns CHIPMUNK_OK, or -1 when the shape is not for it
+int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o, float *l, const int64_t qs[3],
+                            const int64_t ks[3], const int64_t vs[3], const int64_t os[3], int B, int H, int Nq, int Nk,
+                            hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)dense64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    D64Params p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = qs[i], p.ks[i] = ks[i], p.vs[i] = vs[i], p.os[i] = os[i];
+    p.l_out = l;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + WGROWS - 1) / WGROWS;
+    const int64_t grid = (int64_t)B * H * p.G;
+    hipLaunchKernelGGL(dense64_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
