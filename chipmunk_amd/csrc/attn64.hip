@@ -32,7 +32,7 @@ constexpr int LDS_BYTES = 2 * NSL * TB;   // 128 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
 // timing ablations (tools/attn64_ablate.py builds one library per value; results are wrong, only the clock is read):
-// 1 = no exp2 / row sums / packing, 2 = no maxima / s*c - m*c, 4 = no V^T reads, 8 = no K reads, 16 = no DMA, barrier, vmcnt
+// 32 = v_mul instead of v_exp_f32, 1 = no exp2 / row sums / packing, 2 = no maxima / s*c - m*c, 4 = no V^T reads, 8 = no K reads, 16 = no DMA, barrier, vmcnt
 #ifndef A64_ABL
 #define A64_ABL 0
 #endif
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float px[64];       // x = s*c - m*c, then p = exp2(x), of the tile being finished; e = blk*16 + r
     uint32_t pw[2][4][4] = {};   // P^T fragments (qb, key slab u', dword); zero: the first tile's PV multiplies P(-1) = 0
     float m[2] = {-INFINITY, -INFINITY}, nmsc[2] = {0.f, 0.f};
+    float mlag[2] = {-INFINITY, -INFINITY};   // m + the lag (in raw score units): the per-tile check is one compare per query block
     float lacc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float alpha[2] = {1.f, 1.f};
     // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (!(A64_ABL & 1)) {
             static_for<ecum(K), ecum(K + 1)>([&](auto ii) {           // E
                 constexpr int I = decltype(ii)::value;
-                px[I] = __builtin_amdgcn_exp2f(px[I]);
+                if constexpr (A64_ABL & 32) px[I] = px[I] * 0.5f;   // ablation: the price of v_exp_f32 itself
+                else px[I] = __builtin_amdgcn_exp2f(px[I]);
                 pin(px[I]);
             });
             static_for<ecum(K - 1), ecum(K)>([&](auto ii) {           // L
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
             if constexpr (G < 6) finish_step(ic<52 + G>{});
-            if constexpr ((G & 1) == 0 && !(A64_ABL & 8)) {    // K(t+1) fragments, one every other gap (nothing in this phase waits on LDS)
-                constexpr int J = G >> 1;
+            if constexpr (G < 16 && !(A64_ABL & 8)) {    // K(t+1) fragments, one per gap in the first half (nothing in this phase waits
+                constexpr int J = G;                      // on LDS; the last one is 16 gaps old at the end-of-phase wait)
                 lds_k<(J >> 3), (J & 7), KNSL>(kad[J & 7]);
             }
             if constexpr (G == 1 && !(A64_ABL & 2)) {   // ragged / padding tile: its first `dead` LDS rows are not this tile's keys
@@ -330,7 +332,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (G >= 2 && G <= 9 && !(A64_ABL & 2)) {   // maxima of the 32 scores a lane holds per query block: 16 x v_max3 each, two per
                 constexpr int j = G - 2;        // block per gap, the four of a gap in one statement (one boundary pad, not four)
                 constexpr int kb2 = j >> 2, r0 = (j & 3) * 4;
-                if constexpr (j == 0) mx[0] = mx[1] = -INFINITY;
+                if constexpr (j == 0)
+                    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
+                                 : "=&v"(mx[0]), "=&v"(mx[1])
+                                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]));
+                else
                 asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
                              : "+v"(mx[0]), "+v"(mx[1])
                              : "v"(s[kb2 * 2][r0]), "v"(s[kb2 * 2][r0 + 1]), "v"(s[kb2 * 2][r0 + 2]), "v"(s[kb2 * 2][r0 + 3]),
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         P64_MARK(3);
         if constexpr (!(A64_ABL & 2)) {   // the (rare) move of the reference point
             constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
-            if (!__all(mx[0] <= m[0] + LAG_RAW && mx[1] <= m[1] + LAG_RAW)) {
+            if (__builtin_amdgcn_ballot_w64(mx[0] > mlag[0]) | __builtin_amdgcn_ballot_w64(mx[1] > mlag[1])) {
                 moved = true;
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
@@ -370,6 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     lacc[q2][1] *= alpha[q2];
                     m[q2] = m_new;
                     nmsc[q2] = -m_new * SCALE_LOG2E;
+                    mlag[q2] = m_new + LAG_RAW;
                 }
             }
         }
