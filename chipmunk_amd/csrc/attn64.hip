@@ -32,9 +32,12 @@ constexpr int LDS_BYTES = 2 * NSL * TB;   // 128 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
 // timing ablations (tools/attn64_ablate.py builds one library per value; results are wrong, only the clock is read):
-// 32 = v_mul instead of v_exp_f32, 1 = no exp2 / row sums / packing, 2 = no maxima / s*c - m*c, 4 = no V^T reads, 8 = no K reads, 16 = no DMA, barrier, vmcnt
+// 256 = no vmcnt wait, 128 = no s_barrier, 64 = QK MFMAs write accumulator registers instead of VGPRs, 32 = v_mul instead of v_exp_f32, 1 = no exp2 / row sums / packing, 2 = no maxima / s*c - m*c, 4 = no V^T reads, 8 = no K reads, 16 = no DMA, barrier, vmcnt
 #ifndef A64_ABL
 #define A64_ABL 0
+#endif
+#ifndef A64_DMA_POS   // where the eight DMA pieces of a tile are issued: 0 = phase A gaps 0..7, 1 = phase B gaps 16..30 (even), 2 = phase A gaps 16..30 (even)
+#define A64_DMA_POS 0
 #endif
 
 #ifdef ATTN64_PROF
@@ -81,6 +84,11 @@ __device__ __forceinline__ float max2(float a, float b) {
 template <int KB, int QB, int KS>
 __device__ __forceinline__ void mfma_qk(f32x16 &s) {
     constexpr int ka = 192 + (KB * 8 + KS) * 4, qa = 128 + (QB * 8 + KS) * 4;
+    if constexpr (A64_ABL & 64) {   // ablation: the scores accumulate in accumulator registers (wrong, timing only)
+        constexpr int oa = (KB * 2 + QB) * 16;
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], a[%c4:%c5], a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
+        return;
+    }
     if constexpr (KS == 0)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
     else
@@ -267,8 +275,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // K(t+1) and V(t-1) were issued three iterations ago: the issues of the last two iterations may stay in flight
         uint32_t ldsw = w * 4096, ksoff = 0, vsoff = 0;
         if constexpr (!(A64_ABL & 16)) {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(A64_ABL & 256)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if constexpr (!(A64_ABL & 128)) __builtin_amdgcn_s_barrier();
             // (opaque copies: the 32 destination addresses of the four unrolled tiles are sums the loop recomputes with one
             // SALU op each instead of values the compiler hoists and then spills)
             asm volatile("" : "+s"(ldsw));
@@ -284,9 +292,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int G = decltype(gg)::value;
             constexpr int ks = G >> 2, kb = (G >> 1) & 1, qb = G & 1;
             mfma_qk<kb, qb, ks>(s[kb * 2 + qb]);
-            if constexpr (G < 8 && !(A64_ABL & 16)) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2): one piece per gap
-                if constexpr (G < 4) issue_k1(ksoff, ldsw, SL, G);
-                else issue_v1(vsoff, ldsw, (SL + 2) & 3, G - 4);
+            if constexpr (!(A64_ABL & 16) && ((A64_DMA_POS == 0 && G < 8) || (A64_DMA_POS == 2 && G >= 16 && (G & 1) == 0))) {
+                // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2): one piece per gap
+                constexpr int PC = A64_DMA_POS == 0 ? G : (G - 16) >> 1;
+                if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
+                else issue_v1(vsoff, ldsw, (SL + 2) & 3, PC - 4);
             }
             finish_step(ic<20 + G>{});
             if constexpr (G < 16) {   // all sixteen V^T fragments of tile t-1, one per gap: the LDS pipe carries V in phase A and K in
@@ -314,6 +324,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
             if constexpr (G < 6) finish_step(ic<52 + G>{});
+            if constexpr (!(A64_ABL & 16) && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
+                constexpr int PC = (G - 16) >> 1;
+                if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
+                else issue_v1(vsoff, ldsw, (SL + 2) & 3, PC - 4);
+            }
             if constexpr (G < 16 && !(A64_ABL & 8)) {    // K(t+1) fragments, one per gap in the first half (nothing in this phase waits
                 constexpr int J = G;                      // on LDS; the last one is 16 gaps old at the end-of-phase wait)
                 lds_k<(J >> 3), (J & 7), KNSL>(kad[J & 7]);

@@ -21,7 +21,7 @@ if sys.argv[1] == "build":
     os.makedirs(os.path.join(ROOT, "tools", "bin"), exist_ok=True)
     masks = [int(a) for a in sys.argv[2:]] or MASKS
     procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               f"-DA64_ABL={m}", "-o", path(m)] + SRC) for m in masks]
+                               f"-DA64_ABL={m & 0xfff}", f"-DA64_DMA_POS={m >> 12}", "-o", path(m)] + SRC) for m in masks]
     assert all(p.wait() == 0 for p in procs)
 else:
     keep = LIB + ".keep"
