@@ -36,8 +36,17 @@ constexpr float MAX_LAG = 4.0f;
 #ifndef A64_ABL
 #define A64_ABL 0
 #endif
-#ifndef A64_DMA_POS   // where the eight DMA pieces of a tile are issued: 0 = phase A gaps 0..7, 1 = phase B gaps 16..30 (even), 2 = phase A gaps 16..30 (even)
-#define A64_DMA_POS 0
+#ifndef A64_EB   // exp2 steps of a tile beside its own PV-phase gaps 12..31 (EB) and beside the next tile's QK^T phase (EA); the rest
+#define A64_EB 20  // go one per gap into the next PV phase
+#endif
+#ifndef A64_EA
+#define A64_EA 40
+#endif
+#ifndef A64_VSPREAD   // V^T fragment reads: 0 = one per gap in phase A gaps 0..15, 1 = every other gap 0..30
+#define A64_VSPREAD 0
+#endif
+#ifndef A64_DMA_POS   // where the eight DMA pieces of a tile are issued: 0 = phase A gaps 0..7, 1 = phase B gaps 16..30 (even), 2 = phase A gaps
+#define A64_DMA_POS 2  // 16..30 (even; after the V^T reads: 2 718 vs 2 798 cycles per tile for position 0, tools/attn64_cycles.py)
 #endif
 
 #ifdef ATTN64_PROF
@@ -242,7 +251,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //        L_i: row sum, one step behind E;  C_j: bf16 pair j = (2j, 2j+1), one step behind E of its second element.
     //      Slab deadlines (first PV MFMA that reads the fragment): slab 0 at B(t+1) gap 0 (packed by k = 17), slab 1 at gap 8
     //      (k = 31), slab 2 at gap 16 (k = 44), slab 3 at gap 24 (k = 57 = gap 5).
-    auto ecum = [](int k) constexpr { return k <= 0 ? 0 : k <= 20 ? k : k <= 52 ? 20 + (k - 20) + ((k - 20) >> 2) : (k <= 56 ? 8 + k : 64); };
+    static_assert(64 - A64_EB - A64_EA >= 0 && 64 - A64_EB - A64_EA <= 9, "the last steps must finish before gap 12 of the next PV phase");
+    auto ecum = [](int k) constexpr {
+        return k <= 0 ? 0 : k <= 20 ? (k * A64_EB) / 20 : k <= 52 ? A64_EB + ((k - 20) * A64_EA) / 32
+                                                                  : (A64_EB + A64_EA + (k - 52) < 64 ? A64_EB + A64_EA + (k - 52) : 64);
+    };
     auto finish_step = [&](auto kk) __attribute__((always_inline)) {
         constexpr int K = decltype(kk)::value;
         if constexpr (!(A64_ABL & 1)) {
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 else issue_v1(vsoff, ldsw, (SL + 2) & 3, PC - 4);
             }
             finish_step(ic<20 + G>{});
-            if constexpr (G < 16) {   // all sixteen V^T fragments of tile t-1, one per gap: the LDS pipe carries V in phase A and K in
-                constexpr int f = G;  // phase B (each wave reads both tiles whole: 2 x 64 KiB per CU and tile = 1024 LDS cycles)
+            if constexpr (A64_VSPREAD ? (G & 1) == 0 : G < 16) {   // all sixteen V^T fragments of tile t-1: the LDS pipe carries V in phase A and K
+                constexpr int f = A64_VSPREAD ? G >> 1 : G;        // in phase B (each wave reads both tiles whole: 2 x 64 KiB per CU and tile = 1024 LDS cycles)
                 if constexpr (A64_ABL & 4) vf[f] = (u32x4){(uint32_t)t, 1u, 2u, 3u};
                 else vf[f] = vfrag_read(ic<(f & 3)>{}, ic<VSL * TB + (f >> 2) * 4096>{});
             }
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
-            if constexpr (G < 6) finish_step(ic<52 + G>{});
+            if constexpr (G < 12) finish_step(ic<52 + G>{});
             if constexpr (!(A64_ABL & 16) && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
                 constexpr int PC = (G - 16) >> 1;
                 if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);

@@ -19,9 +19,15 @@ def path(mask):
 
 if sys.argv[1] == "build":
     os.makedirs(os.path.join(ROOT, "tools", "bin"), exist_ok=True)
-    masks = [int(a) for a in sys.argv[2:]] or MASKS
-    procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               f"-DA64_ABL={m & 0xfff}", f"-DA64_DMA_POS={m >> 12}", "-o", path(m)] + SRC) for m in masks]
+    # an argument is either an ablation mask (+ 4096 * DMA position) or a tag NAME:-DFOO=1:-DBAR=2 (free-form defines)
+    procs = []
+    for a in sys.argv[2:] or [str(m) for m in MASKS]:
+        if ":" in a:
+            tag, *defs = a.split(":")
+        else:
+            tag, defs = a, [f"-DA64_ABL={int(a) & 0xfff}", f"-DA64_DMA_POS={int(a) >> 12}"]
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                                       *defs, "-o", path(tag)] + SRC))
     assert all(p.wait() == 0 for p in procs)
 else:
     keep = LIB + ".keep"
