@@ -17,6 +17,7 @@
 //   * scheduling across workgroups: longest-first order for ragged key counts, key-split tail with a last-arriver merge
 //     for near-equal items (see launch_attn); no float atomics, every reduction has a fixed order.
 #include "common.h"
+#include "attn_params.h"
 
 namespace {
 
@@ -32,30 +33,6 @@ constexpr int NSTV = NST + 1;  // V ring: one slot deeper, tile t-1's V is read 
 constexpr int KEY_RING_OFF = (NST + NSTV) * TILE_BYTES;
 constexpr int CS_OFF = KEY_RING_OFF + KRING * 256;
 constexpr int ATTN_LDS_BYTES = CS_OFF + 2 * 2 * 4 * KVT * 4;  // column-sum partials [2 iterations][2 tiles][4 waves][KVT]
-
-struct AttnParams {
-    const uint16_t *q, *k, *v;
-    uint16_t *o;
-    const uint16_t *o_in;  // INPLACE only: the accumulation base (o itself for the in-place op, the cache for csp_attn_out)
-    int64_t qs[3], ks[3], vs[3], os[3];
-    const int32_t *indices, *counts;
-    float *l_out;
-    const float *p_in;
-    uint16_t *cs;
-    int cs_stride;
-    int B, H, Nq, Nk, G, idx_stride;
-    float o_scale;
-    // key-split tail (see launch_attn): items >= split_full are handed to `nsplit` workgroups, each over a slice of the
-    // item's key tiles; partial (o, m, l) go through `ws`, the last arriver (ticket) merges and runs the epilogue
-    int split_full, nsplit;
-    float *ws;
-    int32_t *tickets;
-    // optional work plan for ragged key counts (attn_plan_kernel): block i processes item plan[2i] (< 0: nothing), slice
-    // (plan[2i+1] & 0xffff) of (plan[2i+1] >> 16) slices over the item's key tiles; slices of one item are adjacent
-    const int32_t *plan;
-    int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
-    int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
-};
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -757,6 +734,12 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     }
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
+    // option attn_csp64 = 1 sends gathered launches to the one-wave-per-SIMD kernel (attn64.hip: three compute waves + a
+    // loader wave per 192-row group, ONE workgroup per CU).  Off by default: at equal counts it measured +2.7 % (random
+    // keys) / +5.4 % (keys shared between groups) over this file's kernel, but on HunyuanVideo's ragged launches (text /
+    // tail groups 13x longer than the rest, one workgroup per CU) 15.5 vs 14.3 ms.
+    const int o64 = chipmunk_get_option("attn_csp64");
+    const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
              "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
     AttnParams pp = p;
@@ -770,8 +753,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // scratch layout: [tickets: TICKET_BYTES, always left at zero][work order | split partials]
     constexpr size_t TICKET_BYTES = 64 << 10;
     int64_t grid = nblocks;
-    if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768) && !chipmunk_get_option("attn_no_order")) {
-        const int slots = wg_per_cu * device_cu_count();
+    if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768 || want64) && !chipmunk_get_option("attn_no_order")) {
+        const int slots = (want64 ? 1 : wg_per_cu) * device_cu_count();
         const int max_slices = 3 * 2 * device_cu_count();         // 1536 x 104 KB = 160 MB of partials at most
         const int64_t cap = nblocks + max_slices;                 // plan entries == workgroups launched
         const size_t plan_bytes = (size_t)cap * 2 * sizeof(int32_t);
@@ -786,6 +769,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
             pp.ws = (float *)(sc + ws_off);
             pp.xcd_chunks = 0;
             grid = cap;
+            if (want64) return chipmunk_csp64_launch(pp, INPLACE ? 1 : 0, (int)grid, stream);
         }
     }
     // Key-split tail.  Workgroups are dispatched in block order as the 2-per-CU slots free up; with near-equal items

@@ -18,6 +18,7 @@
 // The loop is unrolled over the four ring slots so that every LDS address is base + immediate.
 #include "common.h"
 #include "attn64_regs.h"
+#include "attn_params.h"
 #include <type_traits>
 
 namespace {
@@ -128,30 +129,124 @@ __device__ __forceinline__ f32x4 acc_read4() {
     return (f32x4){a, b, c, d};
 }
 
-struct D64Params {
-    const uint16_t *q, *k, *v;
-    uint16_t *o;
-    int64_t qs[3], ks[3], vs[3], os[3];
-    float *l_out;
-    int B, H, Nq, Nk, G;
-};
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense64_kernel(const D64Params p) {
+// MODE 0: dense -- 256-row workgroups, every wave computes 64 rows and stages its quarter of each tile.
+// MODE 1 / 2: gathered (csp_128_attn / the accumulate forms csp_attn, csp_attn_out) -- one 192-row query group per
+//   workgroup: waves 0..2 compute 64 rows each, wave 3 is the LOADER: it reads the group's index list, forms the per-lane
+//   row offsets and issues every LDS-DMA piece of every tile (32 per tile, ~40 cycles of issue each: a quarter of a
+//   compute wave's tile time when each wave stages its own share).  Three SIMDs of MFMA work out of four measured 90 % of
+//   the four-wave dense kernel's throughput on dense data (the compute waves' tiles get shorter, the chip clocks higher).
+//   Work items come from the device-built plan of attn.hip (longest-first order, heavy items sliced over their key tiles
+//   and merged by the last arriver).
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn64_kernel(const AttnParams p) {
+    constexpr bool GATHER = MODE != 0, INPLACE = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5, l15 = lane & 15, lg = lane >> 4;
-    const int wid = blockIdx.x;
+    // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
+    int wid = blockIdx.x, sp = 0, nsp = 1, slot0 = 0, tix = 0;
+    if constexpr (GATHER) {
+        const int wid0 = wid;
+        wid = p.plan[2 * wid0];
+        if (wid < 0) return;
+        const int meta = p.plan[2 * wid0 + 1];
+        sp = meta & 0xffff, nsp = meta >> 16;
+        slot0 = tix = wid0 - sp;
+    }
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int row0 = g * WGROWS + w * WROWS;
-    const int ntiles = (p.Nk + KT - 1) / KT;
+    const int row0 = g * (GATHER ? 192 : WGROWS) + w * WROWS;
+    const int count = GATHER ? p.counts[(int64_t)bh * p.G + g] : p.Nk;
+    const int valid = count < p.Nk ? count : p.Nk;   // packed positions >= Nk are masked out (csp_128_attn.cu:314)
+    const int ntiles_all = (valid + KT - 1) / KT;
+    const int tbeg = (int)((int64_t)ntiles_all * sp / nsp), tend = (int)((int64_t)ntiles_all * (sp + 1) / nsp);
+    const int ntiles = tend - tbeg;                  // tiles of this workgroup; local tile t = tile tbeg + t of the item
     const int T4 = (ntiles + 3) & ~3;
 
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
     const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
     const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;
+
+    if (GATHER && w == 3) {
+        // ---- the loader wave.  LDS row 4*pc + lg of a tile (piece pc, lane group lg) holds packed position lg*16 + pc of the
+        // tile: lane group lg reads 16 CONSECUTIVE indices into 16 registers and piece pc takes register pc -- no cross-lane
+        // movement (the order of the keys inside a tile is free as long as K, V and the tail mask agree on it).
+        // Indices of four tiles live in a register ring (entry = tile mod 4); iteration t loads tile t+5's, issues K(t+4)
+        // into the slot K(t) left and V(t+2) into the slot of V(t-2).  vmcnt: an iteration is 4 index loads + 32 pieces (16 +
+        // 32 on the unaligned path); at the top of iteration t everything up to iteration t-3 has to have landed -- 72
+        // younger operations, more than the counter can express: vmcnt(63), the loosest wait there is, covers it (a single
+        // wave cannot keep more than 63 KiB of gathers in flight; key*stride as a 24-bit multiply, checked by the host).
+        const int32_t *idx = p.indices + ((int64_t)bh * p.G + g) * p.idx_stride;
+        uint32_t kswz[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kswz[i] = (uint32_t)(l15 ^ (4 * i + lg)) << 4;
+        const uint32_t vswz = (uint32_t)(l15 ^ (lg << 2)) << 4;
+        int ir[4][16];
+        // 16 consecutive indices per lane group: four 16-byte loads when the row is 16-byte aligned and the tile lies inside
+        // the list (every HunyuanVideo / Wan / FLUX launch), dword loads with clamped positions otherwise
+        const bool idx_vec = ((uintptr_t)idx & 15) == 0 && (p.idx_stride & 3) == 0;
+        auto load_idx = [&](int T, int (&dst)[16]) {
+            const int base = (tbeg + T) * KT + lg * 16;
+            if (idx_vec && (tbeg + T) * KT + KT <= p.idx_stride) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const u32x4 v4 = *(const u32x4 *)(idx + base + j4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[j4 * 4 + e] = (int)v4[e];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    int pos = base + j;
+                    pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
+                    dst[j] = idx[pos];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dst[j] = max(0, min(dst[j], p.Nk - 1));   // memory safety for malformed indices
+        };
+        auto all_k = [&](const int (&src)[16], int slot) {
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) blds16(krsrc, __umul24((uint32_t)src[pc], kstride_b) + kswz[pc & 3], 0, smem + slot * TB + pc * 1024);
+        };
+        auto all_v = [&](const int (&src)[16], int slot) {
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) blds16(vrsrc, __umul24((uint32_t)src[pc], vstride_b) + vswz, 0, smem + VRING + slot * TB + pc * 1024);
+        };
+        load_idx(0, ir[0]), load_idx(1, ir[1]), load_idx(2, ir[2]), load_idx(3, ir[3]);
+        all_k(ir[0], 0);
+        all_k(ir[1], 1), all_v(ir[0], 3);
+        all_k(ir[2], 2), all_v(ir[0], 0);
+        all_k(ir[3], 3), all_v(ir[1], 1);
+        load_idx(4, ir[0]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto loader_tile = [&](auto slc, int t) __attribute__((always_inline)) {
+            constexpr int SL = decltype(slc)::value;
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_idx(t + 5, ir[(SL + 1) & 3]);
+            all_k(ir[SL], SL);
+            all_v(ir[(SL + 2) & 3], (SL + 2) & 3);
+        };
+        for (int tb = 0;; tb += 4) {
+            loader_tile(ic<0>{}, tb);
+            if (tb >= T4) break;
+            loader_tile(ic<1>{}, tb + 1);
+            loader_tile(ic<2>{}, tb + 2);
+            loader_tile(ic<3>{}, tb + 3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nsp > 1) {   // the barriers of the slice hand-off below
+            __syncthreads();
+            __syncthreads();
+            if (*(volatile int *)(smem) != nsp - 1) return;
+            __syncthreads();
+        }
+        return;
+    }
 
     // ---- accumulator file: O^T = 0, Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7)
     asm volatile(A64_ZERO_O ::: A64_CLOBBER_ALL);
@@ -207,11 +302,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: K(0), then the issues of "iterations" -3..-1 (iteration i issues K(i+4) and V(i+2); V(-1) does not
     //      exist: V(0) goes into its slot so that the first tile's PV -- P = 0 -- multiplies finite numbers)
-    issue_k(0, 0);
-    issue_k(1, 1), issue_v(0, 3);
-    issue_k(2, 2), issue_v(0, 0);
-    issue_k(3, 3), issue_v(1, 1);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    if constexpr (!GATHER) {
+        issue_k(0, 0);
+        issue_k(1, 1), issue_v(0, 3);
+        issue_k(2, 2), issue_v(0, 0);
+        issue_k(3, 3), issue_v(1, 1);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
     __syncthreads();
     static_for<0, 16>([&](auto i) {
         constexpr int I = decltype(i)::value;
@@ -288,13 +385,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // K(t+1) and V(t-1) were issued three iterations ago: the issues of the last two iterations may stay in flight
         uint32_t ldsw = w * 4096, ksoff = 0, vsoff = 0;
         if constexpr (!(A64_ABL & 16)) {
-            if constexpr (!(A64_ABL & 256)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if constexpr (!(A64_ABL & 256) && !GATHER) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             if constexpr (!(A64_ABL & 128)) __builtin_amdgcn_s_barrier();
             // (opaque copies: the 32 destination addresses of the four unrolled tiles are sums the loop recomputes with one
             // SALU op each instead of values the compiler hoists and then spills)
-            asm volatile("" : "+s"(ldsw));
-            ksoff = (uint32_t)tile_base(t + 4) * kstride_b;
-            vsoff = (uint32_t)tile_base(t + 2) * vstride_b;
+            if constexpr (!GATHER) {
+                asm volatile("" : "+s"(ldsw));
+                ksoff = (uint32_t)tile_base(t + 4) * kstride_b;
+                vsoff = (uint32_t)tile_base(t + 2) * vstride_b;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         P64_MARK(0);
@@ -305,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int G = decltype(gg)::value;
             constexpr int ks = G >> 2, kb = (G >> 1) & 1, qb = G & 1;
             mfma_qk<kb, qb, ks>(s[kb * 2 + qb]);
-            if constexpr (!(A64_ABL & 16) && ((A64_DMA_POS == 0 && G < 8) || (A64_DMA_POS == 2 && G >= 16 && (G & 1) == 0))) {
+            if constexpr (!(A64_ABL & 16) && !GATHER && ((A64_DMA_POS == 0 && G < 8) || (A64_DMA_POS == 2 && G >= 16 && (G & 1) == 0))) {
                 // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2): one piece per gap
                 constexpr int PC = A64_DMA_POS == 0 ? G : (G - 16) >> 1;
                 if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
@@ -330,14 +429,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ======= phase B: O += V(t-1).P(t-1)  ||  tile t-1: steps 52..57; tile t: maxima, X, steps 0..19; K(t+1) -> a[192:255] ====
         float mx[2];
         bool moved = false;
-        const int dead = t * KT - tile_base(t) < KT ? t * KT - tile_base(t) : KT;   // see tile_base: 0 for every full tile
+        // dense: the first `dead` LDS rows of a ragged / padding tile are not this tile's keys (see tile_base; 0 for a full
+        // tile).  gathered: LDS row 4*pc + lg holds packed position lg*16 + pc; positions >= vleft do not exist.
+        const int dead = GATHER ? 0 : (t * KT - tile_base(t) < KT ? t * KT - tile_base(t) : KT);
+        const int vleft = !GATHER ? KT : (t < ntiles ? valid - (tbeg + t) * KT : 0);
         auto phase_b_gap = [&](auto gg) __attribute__((always_inline)) {
             constexpr int G = decltype(gg)::value;
             constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
             if constexpr (G < 12) finish_step(ic<52 + G>{});
-            if constexpr (!(A64_ABL & 16) && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
+            if constexpr (!(A64_ABL & 16) && !GATHER && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
                 constexpr int PC = (G - 16) >> 1;
                 if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
                 else issue_v1(vsoff, ldsw, (SL + 2) & 3, PC - 4);
@@ -347,7 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 lds_k<(J >> 3), (J & 7), KNSL>(kad[J & 7]);
             }
             if constexpr (G == 1 && !(A64_ABL & 2)) {   // ragged / padding tile: its first `dead` LDS rows are not this tile's keys
-                if (dead > 0) {                         // (wave-uniform, last tiles only)
+                if (!GATHER && dead > 0) {              // (wave-uniform, last tiles only)
                     int thr = dead - 4 * hf;            // opaque: the 32 per-register row numbers are compared as immediates
                     asm volatile("" : "+v"(thr));
 #pragma unroll
@@ -355,6 +457,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if ((blk >> 1) * 32 + (r & 3) + 8 * (r >> 2) < thr) s[blk][r] = -INFINITY;
+                }
+                if (GATHER && vleft < KT) {             // element (blk, r, hf) = LDS row (blk>>1)*32 + (r&3) + 8*(r>>2) + 4*hf
+                    int thr = vleft - hf;               // = position (r&3)*16 + (blk>>1)*8 + 2*(r>>2) + hf
+                    asm volatile("" : "+v"(thr));
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((r & 3) * 16 + (blk >> 1) * 8 + 2 * (r >> 2) >= thr) s[blk][r] = -INFINITY;
                 }
             }
             if constexpr (G >= 2 && G <= 9 && !(A64_ABL & 2)) {   // maxima of the 32 scores a lane holds per query block: 16 x v_max3 each, two per
@@ -434,27 +545,114 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P64_END(w, T4 + 1);
 
-    // ---- epilogue: O = O^T / l; a lane holds, per (qb, db), four groups of 4 consecutive d of query row qb*32 + l31
+    // ---- the accumulators leave the accumulator file: o[(qb*4 + db)*16 + r] = O^T element r of block (qb, db); the row
+    //      sums become whole (both lane halves hold the sum over all keys of the query)
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-    static_for<0, 2>([&](auto qq) {
-        constexpr int QB = decltype(qq)::value;
-        float lp = lacc[QB][0] + lacc[QB][1], lo2 = lp;
-        lane_swap32(lp, lo2);
-        const float l = lp + lo2;
-        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
-        const int qrow = row0 + QB * 32 + l31;
-        uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + 4 * hf;
-        static_for<0, 16>([&](auto ii) {
-            constexpr int I = decltype(ii)::value, DB = I >> 2, R4 = I & 3;
-            const f32x4 o4 = acc_read4<(QB * 4 + DB) * 16 + R4 * 4>();
-            u32x2 out;
-            out[0] = pack_bf16x2(o4[0] * inv, o4[1] * inv);
-            out[1] = pack_bf16x2(o4[2] * inv, o4[3] * inv);
-            if (qrow < p.Nq) *(u32x2 *)(op + DB * 32 + R4 * 8) = out;
-        });
-        if (p.l_out && hf == 0 && qrow < p.Nq)
-            p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[QB] * SCALE_LOG2E) * l);
+    float o[128];
+    static_for<0, 32>([&](auto ii) {
+        constexpr int I = decltype(ii)::value;
+        const f32x4 o4 = acc_read4<I * 4>();
+        o[I * 4 + 0] = o4[0], o[I * 4 + 1] = o4[1], o[I * 4 + 2] = o4[2], o[I * 4 + 3] = o4[3];
     });
+    float lq[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float lp = lacc[qb][0] + lacc[qb][1], lo2 = lp;
+        lane_swap32(lp, lo2);
+        lq[qb] = lp + lo2;
+    }
+
+    if constexpr (GATHER) {
+        if (nsp > 1) {
+            // ---- key-sliced item: publish this slice's (o, m, l) -- [132 values][192 compute threads], coalesced -- take a
+            //      ticket; the last arriver folds ALL slices in slice order (the lane layout is the same in every slice:
+            //      the merge is the online-softmax rescale element by element) and alone runs the epilogue.  Same hand-off as
+            //      attn.hip: plain stores -> barrier -> one agent-scope release -> drained -> relaxed ticket; last arriver:
+            //      ticket -> one agent-scope acquire -> barrier -> plain loads.  The loader wave only takes the barriers.
+            constexpr int SLICE_FLOATS = 26 * 256 * 4;   // the scratch launch_attn reserves per slice
+            int *ticket_s = (int *)smem;
+            float *mine = p.ws + (int64_t)(slot0 + sp) * SLICE_FLOATS + tid;
+#pragma unroll
+            for (int i = 0; i < 128; ++i) mine[i * 192] = o[i];
+            mine[128 * 192] = m[0], mine[129 * 192] = m[1], mine[130 * 192] = lq[0], mine[131 * 192] = lq[1];
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait (see guide)
+                *ticket_s = __hip_atomic_fetch_add(p.tickets + tix, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (*ticket_s != nsp - 1) return;
+            if (tid == 0) {
+                __hip_atomic_store(p.tickets + tix, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 128; ++i) o[i] = 0.f;
+            m[0] = m[1] = -INFINITY, lq[0] = lq[1] = 0.f;
+            for (int s2 = 0; s2 < nsp; ++s2) {
+                const float *oth = p.ws + (int64_t)(slot0 + s2) * SLICE_FLOATS + tid;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const float ms = oth[(128 + qb) * 192], ls = oth[(130 + qb) * 192];
+                    const float m_new = fmaxf(m[qb], ms);
+                    if (m_new == -INFINITY) continue;  // nothing so far and an empty slice
+                    const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
+                    const float c = __builtin_amdgcn_exp2f((ms - m_new) * SCALE_LOG2E);
+                    m[qb] = m_new;
+                    lq[qb] = lq[qb] * a + ls * c;
+#pragma unroll
+                    for (int i = 0; i < 64; ++i) o[qb * 64 + i] = o[qb * 64 + i] * a + oth[(qb * 64 + i) * 192] * c;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: O = O^T / l; a lane holds, per (qb, db), four groups of 4 consecutive d of query row qb*32 + l31
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l = lq[qb];
+        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
+        const int qrow = row0 + qb * 32 + l31;
+        if (qrow >= p.Nq) continue;
+        const int64_t ooff = b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + 4 * hf;
+        uint16_t *op = p.o + ooff;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int db = i >> 2, r4 = i & 3;
+            const float *o4 = o + (qb * 4 + db) * 16 + r4 * 4;
+            float x0 = o4[0] * inv, x1 = o4[1] * inv, x2 = o4[2] * inv, x3 = o4[3] * inv;
+            u32x2 out;
+            if constexpr (INPLACE) {
+                // bf16 store of o_scale*result, then bf16 reduce-add into the base (csp_attn.cu:294-300)
+                const u32x2 old = *(const u32x2 *)(p.o_in + ooff + db * 32 + r4 * 8);
+                const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
+                const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
+                out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
+                out[1] = pack_bf16x2(__uint_as_float(old[1] << 16) + a2, __uint_as_float(old[1] & 0xffff0000u) + a3);
+            } else {
+                out[0] = pack_bf16x2(x0, x1);
+                out[1] = pack_bf16x2(x2, x3);
+            }
+            *(u32x2 *)(op + db * 32 + r4 * 8) = out;
+        }
+        if (!GATHER && p.l_out && hf == 0)
+            p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+    }
+}
+
+template <int MODE>
+int launch64(const AttnParams &p, int64_t grid, hipStream_t stream) {
+    auto kern = attn64_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
 }
 
 }  // namespace
@@ -465,22 +663,21 @@ extern "C" int chipmunk_attn64_prof_read(unsigned long long *out) {
 }
 #endif
 
-// dense attention through the one-wave-per-SIMD kernel; returns CHIPMUNK_OK, or -1 when the shape is not for it
+// dense attention through the one-wave-per-SIMD kernel (strides in elements, [batch, head, row])
 int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o, float *l, const int64_t qs[3],
                             const int64_t ks[3], const int64_t vs[3], const int64_t os[3], int B, int H, int Nq, int Nk,
                             hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dense64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
-    D64Params p = {};
+    AttnParams p = {};
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
     for (int i = 0; i < 3; ++i) p.qs[i] = qs[i], p.ks[i] = ks[i], p.vs[i] = vs[i], p.os[i] = os[i];
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + WGROWS - 1) / WGROWS;
-    const int64_t grid = (int64_t)B * H * p.G;
-    hipLaunchKernelGGL(dense64_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
-    CM_LAUNCH_CHECK();
-    return CHIPMUNK_OK;
+    p.o_scale = 1.f;
+    return launch64<0>(p, (int64_t)B * H * p.G, stream);
+}
+
+// gathered attention over the work plan built by launch_attn (attn.hip)
+int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream) {
+    CM_CHECK(p.plan && p.tickets && p.ws, "csp64: work plan missing");
+    return inplace ? launch64<2>(p, grid, stream) : launch64<1>(p, grid, stream);
 }

@@ -1,0 +1,34 @@
+// Launch parameters shared by the attention kernels (attn.hip: the general kernel and the host side; attn64.hip: the
+// one-wave-per-SIMD kernels).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct AttnParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    const uint16_t *o_in;  // INPLACE only: the accumulation base (o itself for the in-place op, the cache for csp_attn_out)
+    int64_t qs[3], ks[3], vs[3], os[3];
+    const int32_t *indices, *counts;
+    float *l_out;
+    const float *p_in;
+    uint16_t *cs;
+    int cs_stride;
+    int B, H, Nq, Nk, G, idx_stride;
+    float o_scale;
+    // key-split tail (see launch_attn): items >= split_full are handed to `nsplit` workgroups, each over a slice of the
+    // item's key tiles; partial (o, m, l) go through `ws`, the last arriver (ticket) merges and runs the epilogue
+    int split_full, nsplit;
+    float *ws;
+    int32_t *tickets;
+    // optional work plan for ragged key counts (attn_plan_kernel): block i processes item plan[2i] (< 0: nothing), slice
+    // (plan[2i+1] & 0xffff) of (plan[2i+1] >> 16) slices over the item's key tiles; slices of one item are adjacent
+    const int32_t *plan;
+    int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
+    int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
+};
+
+
+// attn64.hip: gathered attention over a work plan (p.plan, p.tickets, p.ws set by launch_attn); inplace = 1 for the
+// accumulate forms (o_out = o_in + o_scale * result); `grid` = plan entries
+int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);

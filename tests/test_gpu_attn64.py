@@ -87,3 +87,71 @@ def test_dense64_matches_general_kernel_at_scale(dev):
     _native.set_option("attn_dense64", 0)
     assert_close_bf16(o_b, o_a.float().cpu(), what="dense64 vs general kernel")
     torch.testing.assert_close(l_b, l_a, rtol=1e-3, atol=0)
+
+
+# ---- gathered launches through the three-compute-waves + loader kernel (option attn_csp64 = 1 forces it at test sizes) ----
+
+@pytest.fixture()
+def forced_csp(dev):
+    from chipmunk_amd import _native
+    _native.set_option("attn_csp64", 1)
+    yield
+    _native.set_option("attn_csp64", 0)
+
+
+@pytest.mark.parametrize("n,nk,count", [(384, 384, 128), (1000, 1000, 333), (1152, 1152, 1152), (576, 2000, 64), (200, 640, 7), (960, 960, 0)])
+def test_csp64_random_indices_vs_oracle(dev, forced_csp, n, nk, count):
+    """csp_128_attn: ragged query groups, counts that are not multiples of the 64-key tile (masked tail), fewer keys than a
+    tile, all keys, no keys"""
+    import math
+    from helpers import random_index_sets
+    H = 3
+    q = randn_bf16(1, H, n, 128, seed=n)
+    k = randn_bf16(1, H, nk, 128, seed=nk + 1)
+    v = randn_bf16(1, H, nk, 128, seed=nk + 2)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, nk, count, nk, seed=5)
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what=f"csp64 {n}x{nk} count {count}")
+
+
+@pytest.mark.parametrize("o_scale", [1, -1])
+def test_csp64_inplace_and_out_forms(dev, forced_csp, o_scale):
+    import math
+    from helpers import random_index_sets
+    H, n = 2, 1344
+    q, k, v, base = [randn_bf16(1, H, n, 128, seed=s) for s in (1, 2, 3, 4)]
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, 400, n, seed=9)
+    counts[0, 0, 1] = 37
+    counts[0, 1, 2] = 0
+    ref = base.clone()
+    oracle.csp_attn(q, k, v, ref, inds, counts, o_scale)
+    acc = base.clone().to(dev)
+    torch.ops.chipmunk.csp_attn(q.to(dev), k.to(dev), v.to(dev), acc, inds.to(dev), counts.to(dev), o_scale)
+    assert_close_bf16(acc, ref, atol=3e-2, what="csp64 in place")
+    out = torch.ops.chipmunk.csp_attn_out(q.to(dev), k.to(dev), v.to(dev), base.to(dev), inds.to(dev), counts.to(dev), o_scale)
+    assert torch.equal(out, acc), "the out-of-place form is the in-place form on a copy"
+    assert torch.equal(out[0, 1, 2 * 192:3 * 192].cpu(), base[0, 1, 2 * 192:3 * 192]), "a group without keys keeps the base"
+
+
+def test_csp64_sliced_heavy_items_merge(dev, forced_csp):
+    """a few groups keep ALL keys while the rest keep few: the plan cuts the heavy items into key slices that different
+    workgroups process and the last arriver merges"""
+    import math
+    H, n = 2, 9216
+    q, k, v = [randn_bf16(1, H, n, 128, seed=s) for s in (11, 12, 13)]
+    G = math.ceil(n / 192)
+    gen = torch.Generator().manual_seed(3)
+    inds = torch.stack([torch.randperm(n, generator=gen) for _ in range(H * G)]).view(1, H, G, n).to(torch.int32)
+    counts = torch.full((1, H, G), 96, dtype=torch.int32)
+    counts[0, :, -1] = n
+    counts[0, 0, 3] = n
+    inds[0, :, -1] = torch.arange(n, dtype=torch.int32)
+    inds[0, 0, 3] = torch.arange(n, dtype=torch.int32)
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert_close_bf16(o, o_ref, what="csp64 sliced items")
+    again = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+    assert torch.equal(o, again), "slices fold in slice order: run-to-run deterministic"

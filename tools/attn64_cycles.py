@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "chipmunk_amd", "lib", "libchipmunk_hip.so")
 CTRS = ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"]
 H, N = 2, 119056
-WAVES = H * ((N + 255) // 256) * 4
+WGR = int(os.environ.get("A64_WGROWS", "256"))   # 192 for the loader-wave experiment builds
+WAVES = H * ((N + WGR - 1) // WGR) * 4
 TILES = ((N + 63) // 64 + 3) // 4 * 4 + 1
 
 
