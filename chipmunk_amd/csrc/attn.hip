@@ -940,5 +940,9 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     } else {
         rc = launch_attn<false, false, true>(p, st);
     }
-    return rc != CHIPMUNK_OK ? rc : launch_attn<false, false, false, true>(p, st);
+    if (rc != CHIPMUNK_OK) return rc;
+    // second pass: one wave per 192-row group for long launches (attn64.hip; option attn_colsum64: 1 = always, 2 = never)
+    const int oc = chipmunk_get_option("attn_colsum64");
+    if (Nk >= 64 && (oc == 1 || (oc == 0 && use_dense64(B, H, Nq, Nk)))) return chipmunk_colsum64_launch(p, st);
+    return launch_attn<false, false, false, true>(p, st);
 }

@@ -642,6 +642,172 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- second pass of dense_colsum_attn for long launches: column sums of the softmax over each 192-row query group
+// (reference csrc/attn/dense_colsum_attn.cu:230-277; the general kernel's CSONLY pass, attn.hip, is the small-size form).
+// cs[bh][g][key] = sum over the group's rows q of exp2(s_qk*c + log2 p_q), p = the previous step's 1 / row sum.
+// One WAVE per group (a workgroup = four consecutive groups of one head sharing the K tiles): S = Q.K^T with Q as the A
+// operand, so a lane owns one key column (lane & 31) and the sum over the 192 rows is in-lane adds plus one lane-half
+// swap per tile -- no cross-wave reduction, nothing order-dependent.  All of Q (192 x 128 bf16, pre-scaled by
+// log2e/sqrt(D) like the general kernel's pass) sits in a[0:191], the K fragments of the tile in a[192:255]; the row
+// offsets log2 p_q are the C operand of each block's first MFMA (96 VGPRs), so a score costs one v_exp_f32 and one
+// v_add_f32.  Per 64-key tile six passes (32 query rows each) of 16 MFMAs; the exp2 / adds of a pass run in the gaps of
+// the next one (three score buffers), the K fragments of the next tile are read during the last pass as each
+// fragment's final MFMA has been issued.  A ragged last tile is fetched from the last 64 rows of the key range and its
+// sums are simply stored again (same values).
+template <int QB, int KB, int KS>
+__device__ __forceinline__ void mfma_cs(f32x16 &d, const f32x16 &c0) {
+    constexpr int qa = (QB * 8 + KS) * 4, ka = 192 + (KB * 8 + KS) * 4;
+    if constexpr (KS == 0)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1" : "=&v"(d) : "v"(c0), "i"(qa), "i"(qa + 3), "i"(ka), "i"(ka + 3));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "i"(qa), "i"(qa + 3), "i"(ka), "i"(ka + 3));
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void colsum64_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5, l15 = lane & 15, lg = lane >> 4;
+    const int G4 = (p.G + 3) / 4;
+    const int wid = blockIdx.x;
+    const int bh = wid / G4, g = (wid - bh * G4) * 4 + w;   // this wave's 192-row group (>= p.G: nothing to store)
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int row0 = g * 192;
+    const int ntiles = (p.Nk + KT - 1) / KT;
+    const int T4 = (ntiles + 3) & ~3;
+    const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
+    const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase);
+    const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u;
+
+    // ---- Q fragments (A operand: lane = row l31 of the 32-row block, d = ks*16 + hf*8 .. +7), pre-scaled
+    asm volatile("" ::: A64_CLOBBER_ALL);
+    {
+        const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1];
+        static_for<0, 48>([&](auto f) {
+            constexpr int F = decltype(f)::value, qb = F >> 3, ks = F & 7;
+            const int qrow = row0 + qb * 32 + l31;
+            bf16x8 val = {};
+            if (g < p.G && qrow < p.Nq) val = *(const bf16x8 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = (__bf16)((float)val[e] * SCALE_LOG2E);
+            acc_write4<F * 4>(__builtin_bit_cast(u32x4, val));
+        });
+    }
+    // ---- row offsets: element r of a block is row (r&3) + 8*(r>>2) + 4*hf of the 32-row block
+    f32x16 offs[6];
+#pragma unroll
+    for (int qb = 0; qb < 6; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = row0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const float pl = (g < p.G && qr < p.Nq) ? p.p_in[(int64_t)bh * p.Nq + qr] : 0.f;
+            offs[qb][r] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -1.0e30f;   // (exp2(-huge) = 0; finite keeps 0 * -inf away)
+        }
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    uint32_t kad[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kad[ks] = lds0 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4);
+    uint32_t kofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kofs[i] = (uint32_t)(w * 16 + 4 * i + lg) * kstride_b + ((uint32_t)(l15 ^ (4 * i + lg)) << 4);
+    const int last_base = p.Nk - KT;
+    auto tile_base = [&](int T) { return T * KT < last_base ? T * KT : last_base; };
+    auto issue_k1 = [&](uint32_t soff, uint32_t ldsw, int slot, int i) { blds16(krsrc, kofs[i], soff, smem + ldsw + slot * TB + i * 1024); };
+    auto issue_k = [&](int T, int slot) {
+        const uint32_t soff = (uint32_t)tile_base(T) * kstride_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_k1(soff, w * 4096, slot, i);
+    };
+    issue_k(0, 0), issue_k(1, 1), issue_k(2, 2), issue_k(3, 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __syncthreads();
+    static_for<0, 16>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        lds_k<(I >> 3), (I & 7), 0>(kad[I & 7]);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    f32x16 s[3][2];         // scores of three passes in flight, block kb
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[i][kb][r] = -1.0e30f;   // "passes -1, -2": contribute exp2(-huge) = 0
+    float cacc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [tile parity][kb]
+
+    // one gap's share of the exp2 / adds: exp2 of elements [E0, E0 + 2) of the 32 a lane holds of one pass (buffer BUF; element
+    // E = register E & 15 of block E >> 4), and the adds of the PREVIOUS gap's two exponentials (the add would otherwise wait
+    // out the transcendental's latency).  pe / pe_tp / pe_kb: the exponentials in flight and where they go.
+    float pe[2] = {0.f, 0.f};
+    auto drain2 = [&](auto bufc, auto tpc, auto e0c, auto ptpc, auto pe0c) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, TP = decltype(tpc)::value, E0 = decltype(e0c)::value;
+        constexpr int PTP = decltype(ptpc)::value, PE0 = decltype(pe0c)::value;
+        (void)TP;
+        const float n0 = __builtin_amdgcn_exp2f(s[BUF][E0 >> 4][E0 & 15]);
+        const float n1 = __builtin_amdgcn_exp2f(s[BUF][(E0 + 1) >> 4][(E0 + 1) & 15]);
+        cacc[PTP][PE0 >> 4] += pe[0];
+        cacc[PTP][(PE0 + 1) >> 4] += pe[1];
+        pe[0] = n0, pe[1] = n1;
+        pin(pe[0]), pin(pe[1]), pin(cacc[PTP][PE0 >> 4]);
+    };
+
+    auto tile = [&](auto slc, int t) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slc)::value, TP = SL & 1, KNSL = (SL + 1) & 3;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        uint32_t ldsw = w * 4096;
+        asm volatile("" : "+s"(ldsw));
+        const uint32_t ksoff = (uint32_t)tile_base(t + 4) * kstride_b;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 6>([&](auto qq) {
+            constexpr int QB = decltype(qq)::value;
+            constexpr int PP = SL * 6 + QB;          // pass counter modulo 24 (4 tiles x 6): buffer = PP % 3
+            constexpr int BUF = PP % 3, B1 = (PP + 2) % 3, B2 = (PP + 1) % 3;   // this pass, the previous one, the one before
+            static_for<0, 16>([&](auto gg) {
+                constexpr int G = decltype(gg)::value, ks = G >> 1, kb = G & 1;
+                mfma_cs<QB, kb, ks>(s[BUF][kb], offs[QB]);
+                if constexpr (QB == 0 && G >= 8 && G < 12) issue_k1(ksoff, ldsw, SL, G - 8);   // K(t+4) -> the slot K(t) left
+                if constexpr (QB == 5 && kb == 1) {     // both fragments of this k step have been issued for the last time
+                    lds_k<0, ks, KNSL>(kad[ks]);
+                    lds_k<1, ks, KNSL>(kad[ks]);
+                }
+                // drain: gaps 2..15 take elements 0..27 of the previous pass, gaps 0..1 elements 28..31 of the one before
+                // (the elements of the previous gap: gap 2's predecessor is gap 1 = elements 30, 31 of the pass before the previous
+                // one; gap 0's predecessor is gap 15 of the previous pass = elements 26, 27 of the pass before it)
+                constexpr int TP1 = QB == 0 ? TP ^ 1 : TP, TP2 = QB <= 1 ? TP ^ 1 : TP;   // tile parity of pass P-1 / P-2
+                if constexpr (G > 2) drain2(ic<B1>{}, ic<TP1>{}, ic<(G - 2) * 2>{}, ic<TP1>{}, ic<(G - 3) * 2>{});
+                else if constexpr (G == 2) drain2(ic<B1>{}, ic<TP1>{}, ic<0>{}, ic<TP2>{}, ic<30>{});
+                else if constexpr (G == 1) drain2(ic<B2>{}, ic<TP2>{}, ic<30>{}, ic<TP2>{}, ic<28>{});
+                else drain2(ic<B2>{}, ic<TP2>{}, ic<28>{}, ic<TP2>{}, ic<26>{});
+                if constexpr (QB == 1 && G == 3) {
+                    // the previous tile's sums are complete: lane halves folded with one swap (lanes 0-31: block 0, 32-63: block 1)
+                    float a = cacc[TP ^ 1][0], c = cacc[TP ^ 1][1];
+                    lane_swap32(a, c);
+                    const float tot = a + c;
+                    cacc[TP ^ 1][0] = 0.f, cacc[TP ^ 1][1] = 0.f;
+                    if (g < p.G && t > 0)
+                        p.cs[((int64_t)bh * p.G + g) * p.cs_stride + tile_base(t - 1) + lane] = f32_to_bf16_bits(tot);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K(t+1) fragments have landed
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // tiles 0 .. T4-1 (padding tiles recompute the last one and store the same sums again), then two more passes' worth:
+    // one extra tile whose gaps drain and store tile T4-1
+    for (int tb = 0;; tb += 4) {
+        tile(ic<0>{}, tb);
+        if (tb >= T4) break;
+        tile(ic<1>{}, tb + 1);
+        tile(ic<2>{}, tb + 2);
+        tile(ic<3>{}, tb + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int MODE>
 int launch64(const AttnParams &p, int64_t grid, hipStream_t stream) {
     auto kern = attn64_kernel<MODE>;
@@ -674,6 +840,19 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + WGROWS - 1) / WGROWS;
     p.o_scale = 1.f;
     return launch64<0>(p, (int64_t)B * H * p.G, stream);
+}
+
+// column-sum pass of dense_colsum_attn, one wave per 192-row group (p.p_in, p.cs, p.cs_stride, p.G = groups of 192)
+int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)colsum64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSL * TB);
+        attr_set = true;
+    }
+    const int64_t grid = (int64_t)p.B * p.H * ((p.G + 3) / 4);
+    hipLaunchKernelGGL(colsum64_kernel, dim3((unsigned)grid), dim3(256), NSL * TB, stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
 }
 
 // gathered attention over the work plan built by launch_attn (attn.hip)

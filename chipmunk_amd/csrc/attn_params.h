@@ -32,3 +32,5 @@ struct AttnParams {
 // attn64.hip: gathered attention over a work plan (p.plan, p.tickets, p.ws set by launch_attn); inplace = 1 for the
 // accumulate forms (o_out = o_in + o_scale * result); `grid` = plan entries
 int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
+// attn64.hip: the column-sum pass of dense_colsum_attn for long launches (one wave per 192-row group)
+int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);

@@ -155,3 +155,34 @@ def test_csp64_sliced_heavy_items_merge(dev, forced_csp):
     assert_close_bf16(o, o_ref, what="csp64 sliced items")
     again = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
     assert torch.equal(o, again), "slices fold in slice order: run-to-run deterministic"
+
+
+# ---- the one-wave-per-group column-sum pass (option attn_colsum64 = 1 forces it at test sizes) ----
+
+@pytest.mark.parametrize("n,nk", [(384, 384), (1000, 1000), (1984, 1984), (777, 200), (960, 64), (4160, 768)])
+def test_colsum64_vs_oracle(dev, n, nk):
+    """group counts that are not multiples of four (idle waves), ragged last groups, ragged / padding key tiles (stored
+    twice with the same values), fewer rows than one group"""
+    import math
+    from chipmunk_amd import _native
+    H = 2
+    q = randn_bf16(1, H, n, 128, seed=n)
+    k = randn_bf16(1, H, nk, 128, seed=nk + 1)
+    v = randn_bf16(1, H, nk, 128, seed=nk + 2)
+    q2 = (q.float() + 0.1 * torch.randn(q.shape, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16)
+    _, l0 = oracle.dense_attn(q, k, v)
+    o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(q2, k, v, l0)
+    _native.set_option("attn_colsum64", 1)
+    _native.set_option("attn_dense64", 1)
+    try:
+        o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))
+        again = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))[1]
+    finally:
+        _native.set_option("attn_colsum64", 0)
+        _native.set_option("attn_dense64", 0)
+    G = math.ceil(n / 192)
+    assert cs.shape == (1, H, G, n) and cs.dtype == torch.bfloat16   # Nq columns, the first Nk meaningful (dense_colsum_attn.cu:580-583)
+    assert_close_bf16(o, o_ref, what="colsum64 o")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    assert_close_bf16(cs[..., :nk], cs_ref[..., :nk], atol=2e-3, rtol=3e-2, what="colsum64 cs vs oracle")
+    assert torch.equal(cs[..., :nk], again[..., :nk]), "no order-dependent reduction: run-to-run identical"
