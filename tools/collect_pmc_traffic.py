@@ -36,8 +36,8 @@ def one_pass(counter, what, extra_env=None):
 
 
 C3_KERNELS = {  # HunyuanVideo shapes (bench.py workload hunyuan_c3): kbench cases with all 24 heads
-    "csp_128_attn_c3": "attn_kernel<true, true", "dense_attn_c3": "attn_kernel<false, false, true, false>",
-    "colsum_pass_c3": "attn_kernel<false, false, false, true>",
+    "csp_128_attn_c3": "attn_kernel<true, true", "dense_attn_c3": "attn64_kernel<0>",   # long dense launches: attn64.hip
+    "colsum_pass_c3": "colsum64_kernel",
 }
 
 
