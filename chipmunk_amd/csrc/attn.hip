@@ -402,6 +402,30 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             x = max3(x, s[qb][1][1], s[qb][1][2]);
             return max2(x, s[qb][1][3]);
         };
+        // the steady loop's forms: all three query blocks in ONE statement each (hipcc pads every asm statement that writes a
+        // VGPR with an s_nop and copies operands around single-instruction helpers: 24 statements -> 2 per tile)
+        auto tile_max_x3 = [&](float (&mx)[3]) {
+            asm volatile(
+                "v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %11, %12, %13\n\tv_max3_f32 %2, %19, %20, %21\n\t"
+                "v_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %14, %15\n\tv_max3_f32 %2, %2, %22, %23\n\t"
+                "v_max3_f32 %0, %0, %8, %9\n\tv_max3_f32 %1, %1, %16, %17\n\tv_max3_f32 %2, %2, %24, %25\n\t"
+                "v_max_f32 %0, %0, %10\n\tv_max_f32 %1, %1, %18\n\tv_max_f32 %2, %2, %26"
+                : "=&v"(mx[0]), "=&v"(mx[1]), "=&v"(mx[2])
+                : "v"(s[0][0][0]), "v"(s[0][0][1]), "v"(s[0][0][2]), "v"(s[0][0][3]), "v"(s[0][1][0]), "v"(s[0][1][1]), "v"(s[0][1][2]), "v"(s[0][1][3]),
+                  "v"(s[1][0][0]), "v"(s[1][0][1]), "v"(s[1][0][2]), "v"(s[1][0][3]), "v"(s[1][1][0]), "v"(s[1][1][1]), "v"(s[1][1][2]), "v"(s[1][1][3]),
+                  "v"(s[2][0][0]), "v"(s[2][0][1]), "v"(s[2][0][2]), "v"(s[2][0][3]), "v"(s[2][1][0]), "v"(s[2][1][1]), "v"(s[2][1][2]), "v"(s[2][1][3]));
+        };
+        auto max_rows_x3 = [&](float (&mx)[3]) {   // max over the four 16-lane rows of the wave, three values at once
+            float t0, t1, t2;
+            asm volatile(
+                "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\ts_nop 1\n\t"
+                "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5\n\ts_nop 0\n\t"
+                "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5\n\t"
+                "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\ts_nop 1\n\t"
+                "v_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5\n\ts_nop 0\n\t"
+                "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
+                : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2));
+        };
         float nmsc[3] = {0.f, 0.f, 0.f};            // -m*c, kept beside m (recomputed only when the reference point moves)
         auto exp_block = [&](int qb, float nm) {    // p = exp2(s*c - m*c), in place
 #pragma unroll
@@ -480,19 +504,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                         vr[(db + 2) % 3] = load_v(db + 2);
 #pragma unroll
                         for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
-                        if (db == 0) {
-#pragma unroll
-                            for (int qb = 0; qb < 3; ++qb) {
-                                mx[qb] = tile_max(qb);
-                                pin(mx[qb]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int qb = 0; qb < 3; ++qb) {
-                                mx[qb] = max_rows(mx[qb]);
-                                pin(mx[qb]);
-                            }
-                        }
+                        if (db == 0) tile_max_x3(mx);
+                        else max_rows_x3(mx);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;   // the lag in units of the raw scores
