@@ -688,7 +688,10 @@ def main():
         "config": desc,
         "roofline": roof,
         "kernels": {n: {"launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
-                        "tflops": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 1)} for n, k in kernels.items()},
+                        "tflops": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 1),
+                        "mfma_frac": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFS, 3),
+                        "share_of_kernel_time": round(k["total_ms"] / max(sum(x["total_ms"] for x in kernels.values()), 1e-9), 3),
+                        "traffic": pmc_traffic(n)} for n, k in kernels.items()},
         "dense_gpu_comparator": None if dense_sps is None else {
             "value": dense_sps, "unit": "steps/s", "what": "same loop, F.scaled_dot_product_attention + nn.Linear (rocBLAS/hipBLASLt)",
             "sparse_over_dense": value / dense_sps},
