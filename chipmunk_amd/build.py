@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libchipmunk_hip.so")
 TORCH_EXT = os.path.join(ROOT, "cuda.so")
-HIP_SOURCES = ["attn.hip", "attn64.hip", "mlp.hip", "indexed_io.hip", "capi.hip"]
+HIP_SOURCES = ["attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -30,7 +30,7 @@ def _newer(target: str, deps) -> bool:
 
 def build_hip_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn64_regs.h"), os.path.join(CSRC, "attn_params.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn64_regs.h"), os.path.join(CSRC, "attn_params.h"), os.path.join(CSRC, "attn64_util.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
     if force or _newer(HIP_LIB, deps):
         os.makedirs(LIBDIR, exist_ok=True)
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs

@@ -751,6 +751,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // loader wave per 192-row group, ONE workgroup per CU).  Off by default: at equal counts it measured +2.7 % (random
     // keys) / +5.4 % (keys shared between groups) over this file's kernel, but on HunyuanVideo's ragged launches (text /
     // tail groups 13x longer than the rest, one workgroup per CU) 15.5 vs 14.3 ms.
+    const int o96 = chipmunk_get_option("attn_csp96");   // 1: the two-waves-x-96-rows kernel of attn96.hip (plan as below)
+    const bool want96 = GATHER && !CSONLY && !WRITE_L && o96 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     const int o64 = chipmunk_get_option("attn_csp64");
     const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
@@ -766,7 +768,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // scratch layout: [tickets: TICKET_BYTES, always left at zero][work order | split partials]
     constexpr size_t TICKET_BYTES = 64 << 10;
     int64_t grid = nblocks;
-    if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768 || want64) && !chipmunk_get_option("attn_no_order")) {
+    if (GATHER && !CSONLY && (nblocks >= 2048 || p.Nk >= 32768 || want64 || want96) && !chipmunk_get_option("attn_no_order")) {
         const int slots = (want64 ? 1 : wg_per_cu) * device_cu_count();
         const int max_slices = 3 * 2 * device_cu_count();         // 1536 x 104 KB = 160 MB of partials at most
         const int64_t cap = nblocks + max_slices;                 // plan entries == workgroups launched
@@ -782,6 +784,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
             pp.ws = (float *)(sc + ws_off);
             pp.xcd_chunks = 0;
             grid = cap;
+            if (want96) return chipmunk_csp96_launch(pp, INPLACE ? 1 : 0, (int)grid, stream);
             if (want64) return chipmunk_csp64_launch(pp, INPLACE ? 1 : 0, (int)grid, stream);
         }
     }

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "attn64_regs.h"
 #include "attn_params.h"
+#include "attn64_util.h"
 #include <type_traits>
 
 namespace {
@@ -65,31 +66,6 @@ __device__ unsigned long long g_a64_prof[4 * 8];
 #define P64_END(w, n)
 #endif
 
-template <int V>
-using ic = std::integral_constant<int, V>;
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(ic<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void pin(T &x) {
-    asm volatile("" : "+v"(x));
-}
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float max2(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // S^T block (kb, qb) (+)= K fragment (kb, ks) . Q^T fragment (qb, ks); both operands live in the accumulator file
 template <int KB, int QB, int KS>
 __device__ __forceinline__ void mfma_qk(f32x16 &s) {
@@ -116,19 +92,6 @@ __device__ __forceinline__ void lds_k(uint32_t addr) {
     constexpr int ka = 192 + (KB * 8 + KS) * 4;
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(ka), "i"(ka + 3), "i"(SLOT * TB + KB * 8192) : "memory");
 }
-template <int BASE>
-__device__ __forceinline__ void acc_write4(const u32x4 &v) {
-    asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3\n\ts_nop 1"
-                 ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-}
-template <int BASE>
-__device__ __forceinline__ f32x4 acc_read4() {
-    float a, b, c, d;
-    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"
-                 : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-    return (f32x4){a, b, c, d};
-}
-
 // MODE 0: dense -- 256-row workgroups, every wave computes 64 rows and stages its quarter of each tile.
 // MODE 1 / 2: gathered (csp_128_attn / the accumulate forms csp_attn, csp_attn_out) -- one 192-row query group per
 //   workgroup: waves 0..2 compute 64 rows each, wave 3 is the LOADER: it reads the group's index list, forms the per-lane

@@ -34,3 +34,5 @@ struct AttnParams {
 int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
 // attn64.hip: the column-sum pass of dense_colsum_attn for long launches (one wave per 192-row group)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
+// attn96.hip: gathered attention, two waves x 96 rows per 192-row group, two workgroups per CU (plan as for csp64)
+int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);

@@ -91,12 +91,13 @@ def test_dense64_matches_general_kernel_at_scale(dev):
 
 # ---- gathered launches through the three-compute-waves + loader kernel (option attn_csp64 = 1 forces it at test sizes) ----
 
-@pytest.fixture()
-def forced_csp(dev):
+@pytest.fixture(params=["attn_csp64", "attn_csp96"])
+def forced_csp(dev, request):
+    """both one-wave-per-SIMD gathered kernels: three compute waves + loader (attn64.hip), two waves x 96 rows (attn96.hip)"""
     from chipmunk_amd import _native
-    _native.set_option("attn_csp64", 1)
+    _native.set_option(request.param, 1)
     yield
-    _native.set_option("attn_csp64", 0)
+    _native.set_option(request.param, 0)
 
 
 @pytest.mark.parametrize("n,nk,count", [(384, 384, 128), (1000, 1000, 333), (1152, 1152, 1152), (576, 2000, 64), (200, 640, 7), (960, 960, 0)])

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MASKS = [0, 32, 1, 2, 3, 4, 8, 12, 15, 16, 31]
-SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
+SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
 LIB = os.path.join(ROOT, "chipmunk_amd", "lib", "libchipmunk_hip.so")
 
 

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_a64prof.so")
-SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
+SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
 
 if "--build-only" in sys.argv or not os.path.exists(LIB):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_prof.so")
 
 
 def build(extra=()):
-    src = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
+    src = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DATTN_PROF",
                            *extra, "-o", LIB] + src)
