@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 lds_k<(J >> 3), (J & 7), KNSL>(kad[J & 7]);
             }
             if constexpr (G == 1 && !(A64_ABL & 2)) {   // ragged / padding tile: its first `dead` LDS rows are not this tile's keys
-                if (!GATHER && dead > 0) {              // (wave-uniform, last tiles only)
+                if (!GATHER && __builtin_expect(dead > 0, 0)) {              // (wave-uniform, last tiles only)
                     int thr = dead - 4 * hf;            // opaque: the 32 per-register row numbers are compared as immediates
                     asm volatile("" : "+v"(thr));
 #pragma unroll
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         for (int r = 0; r < 16; ++r)
                             if ((blk >> 1) * 32 + (r & 3) + 8 * (r >> 2) < thr) s[blk][r] = -INFINITY;
                 }
-                if (GATHER && vleft < KT) {             // element (blk, r, hf) = LDS row (blk>>1)*32 + (r&3) + 8*(r>>2) + 4*hf
+                if (GATHER && __builtin_expect(vleft < KT, 0)) {             // element (blk, r, hf) = LDS row (blk>>1)*32 + (r&3) + 8*(r>>2) + 4*hf
                     int thr = vleft - hf;               // = position (r&3)*16 + (blk>>1)*8 + 2*(r>>2) + hf
                     asm volatile("" : "+v"(thr));
 #pragma unroll
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         P64_MARK(4);
         static_for<12, 32>(phase_b_gap);
         P64_MARK(5);
-        if (moved) {   // O_t = alpha (O_{t-1} + P_{t-1} V_{t-1}): after the pending PV, before the next one
+        if (__builtin_expect(moved, 0)) {   // (cold: ~18 KiB of register-by-register code leaves the loop's I-cache footprint) O_t = alpha (O_{t-1} + P_{t-1} V_{t-1}): after the pending PV, before the next one
             float tmp;
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A64_SCALE_QB0 : "=&v"(tmp) : "v"(alpha[0]));
             asm volatile(A64_SCALE_QB1 : "=&v"(tmp) : "v"(alpha[1]));

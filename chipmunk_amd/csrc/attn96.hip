@@ -54,6 +54,21 @@ __device__ __forceinline__ void lds_k(uint32_t addr) {
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(ka), "i"(ka + 3), "i"(SLOT * TB) : "memory");
 }
 
+#ifdef ATTN96_PROF
+// cycle anatomy (tools/attn96_prof.py builds a separate library with -DATTN96_PROF): s_memtime at the segment boundaries
+// of every tile, summed per segment, both waves of one mid-grid workgroup.  Not part of the product build.
+__device__ unsigned long long g_a96_prof[2 * 8];
+#define P96_DECL unsigned long long pt_ = 0, pacc_[7] = {0, 0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == 700
+#define P96_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define P96_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define P96_END(w, n) do { if (prof_on_ && lane == 0) { for (int i_ = 0; i_ < 7; ++i_) g_a96_prof[(w) * 8 + i_] = pacc_[i_]; g_a96_prof[(w) * 8 + 7] = (n); } } while (0)
+#else
+#define P96_DECL
+#define P96_START()
+#define P96_MARK(i)
+#define P96_END(w, n)
+#endif
+
 template <bool INPLACE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void csp96_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,192 +180,180 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_for<0, 8>([&](auto i) { lds_k<decltype(i)::value, 0>(kad[decltype(i)::value]); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    f32x16 s[3];                 // S^T(t) of the three query blocks, then x and p IN PLACE
-    u32x4 pw0[3] = {};           // P^T fragments of key slab 0 (rewritten once the pending PV has read them)
-    u32x4 pw1[3] = {};           // ... of key slab 1 (rewritten after the last MFMA of the phase: a second buffer does not fit)
+    // ---- main loop: ONE stream of 48 MFMAs per 32-key tile, QK^T and PV strictly alternating (slot sigma = 0..47):
+    //   even sigma: S(t)[qb] += K(t)[ks] . Q^T[qb][ks], qb = sigma/16, ks = (sigma%16)/2 -- query block by query block, so
+    //               block qb's scores are complete at sigma = 16 qb + 14 and its softmax can start while the other blocks'
+    //               MFMAs are still running (a dependent chain on one accumulator, but every other MFMA is a PV one);
+    //   odd sigma = 2i+1: the PV element that is three V^T fragment reads old: O[qb'] += V^T . P^T, elements in
+    //               query-block-major order j = qb'*8 + slab*4 + db, stream shifted by three: i < 3 runs tile t-2's j = 21 + i,
+    //               i >= 3 tile t-1's j = i - 3; then the read of fragment i of V(t-1) into the 4-deep window.
+    // The softmax of a block is a 31-slot pipeline (maxima, [rare] reference update + rescale of that block's 64
+    // accumulator registers, then x / exp2 / row sum / bf16 pair, one instruction per stage and slot); the three blocks'
+    // pipelines are staggered by 16 slots, block 1 runs over the tile seam and block 2 entirely in the next tile, so the
+    // VALU load is ~5 issues per slot everywhere and every P^T fragment is complete before the first PV MFMA that reads it
+    // and written only after the last one that read its predecessor.  K(t+1) fragment ks is re-read right after block 2's
+    // MFMA on k step ks; the Q^T block-1 window is 4 k steps deep.  All LDS reads are asm, waited for by count inside
+    // the consuming MFMA's statement (reads return in order; the counts are lower bounds of the younger reads in flight).
+    f32x16 s[3];
+#pragma unroll
+    for (int q2 = 0; q2 < 3; ++q2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[q2][r] = -INFINITY;   // "tile -1": exp2 -> p = 0
+#pragma unroll
+    for (int r = 0; r < 7; ++r) s[1][r] = 0.f;   // (block 1's first seven elements are past the exp2 stage at the tile seam: p = 0)
+    u32x4 pw[3][2] = {};         // P^T fragments (block, key slab)
+    u32x4 vfw[4] = {};           // V^T fragment window (zero: the first PV elements multiply P = 0 by it)
+    u32x4 q1w[4];                // Q^T block-1 window
     float m[3] = {-INFINITY, -INFINITY, -INFINITY}, nmsc[3] = {0.f, 0.f, 0.f}, mlag[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lacc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    float alpha[3] = {1.f, 1.f, 1.f};
+    int vl_prev = KT;            // packed positions that exist in the previous tile (its block 2 is masked in this one)
 
-    auto vfrag_read = [&](auto dbc, auto offc) __attribute__((always_inline)) {
+    auto vfrag_read = [&](auto dbc, auto offc, u32x4 &dst) __attribute__((always_inline)) {
         constexpr int DB = decltype(dbc)::value, OFF = decltype(offc)::value;
         u32x2 lo, hi;
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
                      : "=v"(lo), "=v"(hi) : "v"(vad[DB]), "i"(OFF), "i"(OFF + 2048) : "memory");
-        return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        dst = (u32x4){lo[0], lo[1], hi[0], hi[1]};
     };
-    // softmax element i of a lane's 48 scores per tile, in key-slab order: slab = i / 24, block qb = (i % 24) / 8,
-    // register r = slab*8 + i % 8
-    auto ecum = [](int n) constexpr { return n <= 0 ? 0 : n >= 13 ? 48 : (n * 48) / 13; };
-
-    u32x4 q1[2];   // Q^T block 1, fragment window (k step parity); fragments 0 and 1 of a tile are read at the end of the tile before
-    auto q1_read = [&](auto ksc) __attribute__((always_inline)) {
+    auto q1_read = [&](auto ksc, u32x4 &dst) __attribute__((always_inline)) {
         constexpr int KS = decltype(ksc)::value;
         const uint32_t addr = qad + (kad[KS] - lds0 - l31 * 256);
-        u32x4 fr;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fr) : "v"(addr) : "memory");
-        q1[KS & 1] = fr;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
     };
-    q1_read(ic<0>{});
-    q1_read(ic<1>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]));
+    // dead packed positions of a ragged / padding tile -> -inf (wave-uniform, last tiles only).  Element (r, hf) of a block is
+    // LDS row (r&3) + 8*(r>>2) + 4*hf; row 4*pc + lg holds position (pc>>2)*16 + lg*4 + (pc&3) = (r>>3)*16 + (r&3)*4 + 2*((r>>2)&1) + hf
+    auto mask_block = [&](f32x16 &sq, int vleft) __attribute__((always_inline)) {
+        if (__builtin_expect(vleft < KT, 0)) {
+            int thr = vleft - hf;   // opaque: the 16 per-register constants are compared as immediates
+            asm volatile("" : "+v"(thr));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r >> 3) * 16 + (r & 3) * 4 + 2 * ((r >> 2) & 1) >= thr) sq[r] = -INFINITY;
+        }
+    };
+    // maxima of the 16 scores a lane holds of a block: step 0 = v_max + v_max3 on registers 0..3, steps 1..3 two v_max3 each
+    auto max_step = [&](auto stepc, const f32x16 &sq, float &mx) __attribute__((always_inline)) {
+        constexpr int K = decltype(stepc)::value, r0 = K * 4;
+        if constexpr (K == 0)
+            asm volatile("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "=&v"(mx) : "v"(sq[0]), "v"(sq[1]), "v"(sq[2]), "v"(sq[3]));
+        else
+            asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(mx) : "v"(sq[r0]), "v"(sq[r0 + 1]), "v"(sq[r0 + 2]), "v"(sq[r0 + 3]));
+    };
+    auto max_halves = [&](float &mx) __attribute__((always_inline)) {   // the other 16 keys of the block live in lane ^ 32
+        float t0;
+        asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(mx), "=&v"(t0));
+    };
+    // the (rare) move of block QB's reference point; the pending PV of that block has been issued at least two slots ago
+    auto update_block = [&](auto qq, float mx) __attribute__((always_inline)) {
+        constexpr int QB = decltype(qq)::value;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > mlag[QB]) != 0, 0)) {
+            constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
+            const float m_new = max2(m[QB], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m[QB] - m_new) * SCALE_LOG2E);
+            lacc[QB][0] *= alpha;
+            lacc[QB][1] *= alpha;
+            m[QB] = m_new;
+            nmsc[QB] = -m_new * SCALE_LOG2E;
+            mlag[QB] = m_new + LAG_RAW;
+            float tmp;
+            if constexpr (QB == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB0 : "=&v"(tmp) : "v"(alpha));
+            if constexpr (QB == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB1 : "=&v"(tmp) : "v"(alpha));
+            if constexpr (QB == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB2 : "=&v"(tmp) : "v"(alpha));
+        }
+    };
+    // window slot W (0..23) of block QB's x / exp2 / row sum / pack pipeline, in place on its score registers
+    auto window = [&](auto qq, auto wc) __attribute__((always_inline)) {
+        constexpr int QB = decltype(qq)::value, W = decltype(wc)::value;
+        if constexpr (W < 4) {
+            static_for<4 * W, 4 * W + 4>([&](auto ee) {
+                constexpr int E = decltype(ee)::value;
+                float x = __builtin_fmaf(s[QB][E], SCALE_LOG2E, nmsc[QB]);
+                pin(x);
+                s[QB][E] = x;
+            });
+        }
+        if constexpr (W >= 1 && W <= 16) {
+            float e = __builtin_amdgcn_exp2f(s[QB][W - 1]);
+            pin(e);
+            s[QB][W - 1] = e;
+        }
+        if constexpr (W >= 2 && W <= 17) {
+            lacc[QB][W & 1] += s[QB][W - 2];
+            pin(lacc[QB][W & 1]);
+        }
+        if constexpr (W >= 5 && W <= 19 && (W & 1) == 1) {
+            constexpr int K = (W - 5) >> 1;   // pair (2K, 2K+1): slab K >> 2, dword K & 3
+            uint32_t pk = pack_bf16x2(s[QB][2 * K], s[QB][2 * K + 1]);
+            pin(pk);
+            pw[QB][K >> 2][K & 3] = pk;
+        }
+    };
 
+    P96_DECL;
+    P96_START();
     auto tile = [&](auto slc, int t) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slc)::value, PAR = SL & 1;
+        constexpr int SL = decltype(slc)::value;
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago; an iteration is 8 pieces + 1 (4) index loads
         if (idx_vec) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        P96_MARK(0);
         ir[(SL + 1) & 3] = load_idx(t + 5);
+        const int vl_cur = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist
+        float mxa, mxb, mxc;   // block maxima: this tile's block 0, this tile's block 1, the previous tile's block 2
         __builtin_amdgcn_sched_barrier(0);
-
-        u32x4 vf[8];
-        // ================= phase A: S(t) = K(t).Q^T  ||  V^T(t-1) -> registers, DMA of K(t+4) / V(t+2) =================
-        static_for<0, 24>([&](auto gg) {
-            constexpr int G = decltype(gg)::value, ks = G / 3, qb = G % 3;
-            if constexpr (qb == 1) {
-                // the fragment of this k step has landed: LDS operations return in order, the count is the number of younger
-                // ones at this point (window reads, V^T fragment reads of gaps 0..3), enumerated by hand
-                // (fragments 0 and 1 were read -- and waited for -- at the end of the previous tile)
-                constexpr int YOUNGER = ks == 2 ? 7 : ks == 7 ? 0 : 1;
-                if constexpr (ks >= 2) asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(q1[ks & 1]) : "i"(YOUNGER));
+        static_for<0, 48>([&](auto sg) {
+            constexpr int SG = decltype(sg)::value;
+            if constexpr ((SG & 1) == 0) {   // ---- QK^T
+                constexpr int qb = SG / 16, ks = (SG % 16) / 2, ka = 192 + ks * 4, qa = 224 + ks * 4;
+                if constexpr (qb == 2) {
+                    if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
+                } else {   // (lgkmcnt(6): the K fragment re-read / the window fragment has at least six younger reads behind it)
+                    const u32x4 &qf = qb == 0 ? qv[ks] : q1w[ks & 3];
+                    if constexpr (ks == 0) asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
+                    else asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
+                }
+                if constexpr (SG % 4 == 2 && SG < 32) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2)
+                    constexpr int PC = (SG - 2) / 4;
+                    if constexpr (PC < 4) issue_k1(ir[SL], SL, PC);
+                    else issue_v1(ir[(SL + 2) & 3], (SL + 2) & 3, PC - 4);
+                }
+            } else {                         // ---- PV
+                constexpr int I = (SG - 1) / 2, J = (I + 21) % 24, qbp = J / 8, up = (J % 8) / 4, db = J % 4, oa = (qbp * 4 + db) * 16;
+                asm volatile("s_waitcnt lgkmcnt(4)\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
+                             ::"v"(vfw[J & 3]), "v"(pw[qbp][up]), "i"(oa), "i"(oa + 15));
+                vfrag_read(ic<(I % 4)>{}, ic<VSL * TB + ((I % 8) / 4) * 4096>{}, vfw[I & 3]);   // fragment I of V(t-1): d block I%4, slab (I%8)/4
+                if constexpr (SG >= 9 && SG <= 23) q1_read(ic<(SG - 9) / 2>{}, q1w[((SG - 9) / 2) & 3]);
+                if constexpr (SG >= 33) lds_k<(SG - 33) / 2, KNSL>(kad[(SG - 33) / 2]);
             }
-            mfma_qk<qb, ks>(s[qb], qb == 0 ? qv[ks] : q1[ks & 1]);
-            if constexpr (qb == 1 && ks + 2 < 8) q1_read(ic<ks + 2>{});
-            if constexpr (G < 4) vf[G] = vfrag_read(ic<G>{}, ic<VSL * TB>{});   // slab 0; slab 1 follows in phase B, register by register
-            if constexpr (G >= 8 && (G & 1) == 0) {
-                constexpr int PC = (G - 8) >> 1;
-                if constexpr (PC < 4) issue_k1(ir[SL], SL, PC);
-                else issue_v1(ir[(SL + 2) & 3], (SL + 2) & 3, PC - 4);
-            }
+            // ---- the three softmax pipelines
+            if constexpr (SG == 0) mask_block(s[2], vl_prev);                       // block 2 of tile t-1
+            if constexpr (SG >= 1 && SG <= 4) max_step(ic<SG - 1>{}, s[2], mxc);
+            if constexpr (SG == 5) max_halves(mxc);
+            if constexpr (SG == 7) update_block(ic<2>{}, mxc);
+            if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{});
+            if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{});                  // block 1 of tile t-1, second part
+            if constexpr (SG == 16) mask_block(s[0], vl_cur);                       // block 0 of tile t
+            if constexpr (SG >= 17 && SG <= 20) max_step(ic<SG - 17>{}, s[0], mxa);
+            if constexpr (SG == 21) max_halves(mxa);
+            if constexpr (SG == 23) update_block(ic<0>{}, mxa);
+            if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{});
+            if constexpr (SG == 32) mask_block(s[1], vl_cur);                       // block 1 of tile t
+            if constexpr (SG >= 33 && SG <= 36) max_step(ic<SG - 33>{}, s[1], mxb);
+            if constexpr (SG == 37) max_halves(mxb);
+            if constexpr (SG == 39) update_block(ic<1>{}, mxb);
+            if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{});
             __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ================= phase B: O += V(t-1).P(t-1)  ||  the softmax of tile t, in place; K(t+1) -> a[192:223] ========
-        float mx[3];
-        bool moved = false;
-        const int vleft = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist
-        auto gap = [&](auto gg) __attribute__((always_inline)) {
-            constexpr int G = decltype(gg)::value, up = G / 12, db = (G % 12) / 3, qb = G % 3;
-            const u32x4 &pf = up == 0 ? pw0[qb] : pw1[qb];
-            // the V^T fragments of slab 1 are read as the slab-0 fragment of the same d block has been used for the last time
-            // (nine gaps before their own first use); two waits cover them
-            if constexpr (G == 12) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vf[4]), "+v"(vf[5]), "+v"(vf[6]));   // (the fourth's two reads, one gap old, may stay in flight)
-            if constexpr (G == 21) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[7]));
-            mfma_pv<qb, db>(vf[up * 4 + db], pf);
-            if constexpr (G < 8) lds_k<G, KNSL>(kad[G]);
-            if constexpr (G < 12 && G % 3 == 2) vf[4 + G / 3] = vfrag_read(ic<G / 3>{}, ic<VSL * TB + 4096>{});
-            if constexpr (G == 15) q1_read(ic<0>{});   // the next tile's first two Q^T block-1 fragments (same data every tile)
-            if constexpr (G == 16) q1_read(ic<1>{});
-            if constexpr (G == 1) {
-                if (vleft < KT) {
-                    // element (qb, r, hf) is LDS row (r&3) + 8*(r>>2) + 4*hf of the tile; row 4*pc + lg holds packed position
-                    // (pc>>2)*16 + lg*4 + (pc&3) = (r>>3)*16 + (r&3)*4 + 2*((r>>2)&1) + hf; positions >= vleft do not exist
-                    int thr = vleft - hf;   // opaque: the 16 per-register constants are compared as immediates
-                    asm volatile("" : "+v"(thr));
-#pragma unroll
-                    for (int q2 = 0; q2 < 3; ++q2)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if ((r >> 3) * 16 + (r & 3) * 4 + 2 * ((r >> 2) & 1) >= thr) s[q2][r] = -INFINITY;
-                }
-            }
-            if constexpr (G >= 2 && G <= 5) {   // maxima of the 16 scores a lane holds per block: v_max + 7 x v_max3, two ops per block per gap
-                constexpr int j = G - 2, r0 = j * 4;
-                if constexpr (j == 0)
-                    asm volatile("v_max_f32 %0, %3, %4\n\tv_max_f32 %1, %7, %8\n\tv_max_f32 %2, %11, %12\n\t"
-                                 "v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %9, %10\n\tv_max3_f32 %2, %2, %13, %14"
-                                 : "=&v"(mx[0]), "=&v"(mx[1]), "=&v"(mx[2])
-                                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]),
-                                   "v"(s[2][0]), "v"(s[2][1]), "v"(s[2][2]), "v"(s[2][3]));
-                else
-                    asm volatile("v_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max3_f32 %2, %2, %11, %12\n\t"
-                                 "v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %9, %10\n\tv_max3_f32 %2, %2, %13, %14"
-                                 : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2])
-                                 : "v"(s[0][r0]), "v"(s[0][r0 + 1]), "v"(s[0][r0 + 2]), "v"(s[0][r0 + 3]), "v"(s[1][r0]), "v"(s[1][r0 + 1]),
-                                   "v"(s[1][r0 + 2]), "v"(s[1][r0 + 3]), "v"(s[2][r0]), "v"(s[2][r0 + 1]), "v"(s[2][r0 + 2]), "v"(s[2][r0 + 3]));
-            }
-            if constexpr (G == 6) {   // the other half of the keys lives in lane ^ 32
-                float t0, t1, t2;
-                asm volatile("v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\ts_nop 1\n\t"
-                             "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5\n\ts_nop 0\n\t"
-                             "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
-                             : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2));
-            }
-            if constexpr (G >= 8 && G < 20) {   // X: x = s*c - m*c in place, four elements per gap
-                static_for<(G - 8) * 4, (G - 7) * 4>([&](auto ii) {
-                    constexpr int I = decltype(ii)::value, q2 = (I % 24) / 8, r = (I / 24) * 8 + I % 8;
-                    float x = __builtin_fmaf(s[q2][r], SCALE_LOG2E, nmsc[q2]);
-                    pin(x);   // (the scalar, not the tuple: pinning the 16-register tuples costs ~40 VGPRs of liveness)
-                    s[q2][r] = x;
-                });
-            }
-            if constexpr (G >= 9 && G < 22) {   // E: p = exp2(x) in place
-                static_for<ecum(G - 9), ecum(G - 8)>([&](auto ii) {
-                    constexpr int I = decltype(ii)::value, q2 = (I % 24) / 8, r = (I / 24) * 8 + I % 8;
-                    float e = __builtin_amdgcn_exp2f(s[q2][r]);
-                    pin(e);
-                    s[q2][r] = e;
-                });
-            }
-            if constexpr (G >= 10 && G < 23) {  // L: row sums, one gap behind the exponentials
-                static_for<ecum(G - 10), ecum(G - 9)>([&](auto ii) {
-                    constexpr int I = decltype(ii)::value, q2 = (I % 24) / 8, r = (I / 24) * 8 + I % 8;
-                    lacc[q2][I & 1] += s[q2][r];
-                    pin(lacc[q2][I & 1]);
-                });
-            }
-            if constexpr (G >= 17 && G < 21) {  // C, slab 0: three bf16 pairs per gap (the pending PV has left slab 0 behind at gap 12)
-                static_for<(G - 17) * 3, (G - 16) * 3>([&](auto jj) {
-                    constexpr int J = decltype(jj)::value, q2 = J / 4, d = J % 4;
-                    uint32_t pk = pack_bf16x2(s[q2][2 * d], s[q2][2 * d + 1]);
-                    pin(pk);
-                    pw0[q2][d] = pk;
-                });
-            }
-
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        static_for<0, 8>(gap);
-        {   // the (rare) move of the reference point
-            constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
-            if (__builtin_amdgcn_ballot_w64(mx[0] > mlag[0]) | __builtin_amdgcn_ballot_w64(mx[1] > mlag[1]) |
-                __builtin_amdgcn_ballot_w64(mx[2] > mlag[2])) {
-                moved = true;
-#pragma unroll
-                for (int q2 = 0; q2 < 3; ++q2) {
-                    const float m_new = max2(m[q2], mx[q2]);
-                    alpha[q2] = __builtin_amdgcn_exp2f((m[q2] - m_new) * SCALE_LOG2E);
-                    lacc[q2][0] *= alpha[q2];
-                    lacc[q2][1] *= alpha[q2];
-                    m[q2] = m_new;
-                    nmsc[q2] = -m_new * SCALE_LOG2E;
-                    mlag[q2] = m_new + LAG_RAW;
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<8, 24>(gap);
-        static_for<0, 12>([&](auto jj) {   // C, slab 1: the pending PV has issued its last MFMA on the old fragments
-            constexpr int J = decltype(jj)::value, q2 = J / 4, d = J % 4;
-            pw1[q2][d] = pack_bf16x2(s[q2][8 + 2 * d], s[q2][8 + 2 * d + 1]);
-        });
-        pin(lacc[0][0]), pin(lacc[0][1]), pin(lacc[1][0]), pin(lacc[1][1]), pin(lacc[2][0]), pin(lacc[2][1]);
-        if (moved) {   // O_t = alpha (O_{t-1} + P_{t-1} V_{t-1}): after the pending PV, before the next one
-            float tmp;
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB0 : "=&v"(tmp) : "v"(alpha[0]));
-            asm volatile(A96_SCALE_QB1 : "=&v"(tmp) : "v"(alpha[1]));
-            asm volatile(A96_SCALE_QB2 : "=&v"(tmp) : "v"(alpha[2]));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]));   // the window's first two and the K(t+1) fragments have landed
-        __builtin_amdgcn_sched_barrier(0);
+        vl_prev = vl_cur;
+        P96_MARK(1);
     };
 
-    // tiles 0 .. T4-1 (padding tiles are fully masked), then one more pass whose phase B accumulates tile T4-1
+    // tiles 0 .. T4-1 (padding tiles are fully masked), one more tile's worth of slots for the pipelines in flight, then the
+    // last three PV elements of block 2
     for (int tb = 0;; tb += 4) {
         tile(ic<0>{}, tb);
         if (tb >= T4) break;
@@ -358,7 +361,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tile(ic<2>{}, tb + 2);
         tile(ic<3>{}, tb + 3);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfw[1]), "+v"(vfw[2]), "+v"(vfw[3]));
+    mfma_pv<2, 1>(vfw[1], pw[2][1]);
+    mfma_pv<2, 2>(vfw[2], pw[2][1]);
+    mfma_pv<2, 3>(vfw[3], pw[2][1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P96_END(w, T4 + 1);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 
     float lq[3];
@@ -475,6 +483,12 @@ int launch96(const AttnParams &p, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef ATTN96_PROF
+extern "C" int chipmunk_attn96_prof_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a96_prof), sizeof(g_a96_prof)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 // gathered attention over the work plan built by launch_attn (attn.hip); inplace = 1 for the accumulate forms
 int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream) {

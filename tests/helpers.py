@@ -25,8 +25,9 @@ def assert_close_bf16(a, b, atol=2e-2, rtol=2e-2, what=""):
     a32, b32 = a.float().cpu(), b.float().cpu()
     diff = (a32 - b32).abs()
     tol = atol + rtol * b32.abs()
-    bad = diff > tol
-    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} elements off, max abs diff {diff.max().item():.4g}"
+    bad = ~(diff <= tol)   # (not `diff > tol`: a NaN on either side must count as a mismatch)
+    assert not bad.any(), (f"{what}: {int(bad.sum())} / {bad.numel()} elements off ({int(torch.isnan(a32).sum())} NaN), "
+                           f"max abs diff {torch.nan_to_num(diff, nan=float('inf')).max().item():.4g}")
 
 
 def structured_qkv(H, N, n_hot, step, layer, seed=31337, gain=6.0):
