@@ -29,7 +29,7 @@ def measure(tag):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "dense64" in row["Kernel_Name"]:
+            if "attn64_kernel<0>" in row["Kernel_Name"]:
                 per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     tf = [l for l in r.stdout.splitlines() if "TFLOP" in l]
     vals = {c: sum(per[c].values()) / max(len(per[c]), 1) / WAVES / TILES * 4 for c in CTRS}   # quad-cycles -> cycles per wave per tile
