@@ -817,11 +817,25 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     return CHIPMUNK_OK;
 }
 
-// one-wave-per-SIMD kernel for long dense launches (attn64.hip); option attn_dense64: 0 = by size, 1 = always, 2 = never
+// The one-workgroup-per-CU kernels of attn64.hip pay when their workgroups fill the rounds they occupy: at least one round,
+// at most a quarter of the last one empty (FLUX dense: 408 workgroups = 80 % of two rounds, 220 vs 268 us; a
+// head-parallel rank's single HunyuanVideo head: 466 = 91 %, 5.97 vs 7.33 ms), and at least 1 024 keys to amortise the
+// per-workgroup prologue.
+bool fills_rounds(int64_t nwg, int Nk) {
+    const int64_t cus = device_cu_count(), rounds = (nwg + cus - 1) / cus;
+    return nwg >= cus && nwg * 4 >= 3 * rounds * cus && Nk >= 1024;
+}
+// dense attention (256-row workgroups); option attn_dense64: 0 = by size, 1 = always, 2 = never
 bool use_dense64(int B, int H, int Nq, int Nk) {
     const int o = chipmunk_get_option("attn_dense64");
     if (o) return o == 1 && Nk >= 64;
-    return (int64_t)B * H * ((Nq + 255) / 256) >= 3 * (int64_t)device_cu_count() && Nk >= 2048;
+    return fills_rounds((int64_t)B * H * ((Nq + 255) / 256), Nk);
+}
+// column-sum pass (a workgroup = four 192-row groups of a head); option attn_colsum64 likewise
+bool use_colsum64(int B, int H, int Nq, int Nk) {
+    const int o = chipmunk_get_option("attn_colsum64");
+    if (o) return o == 1 && Nk >= 64;
+    return fills_rounds((int64_t)B * H * (((Nq + QG - 1) / QG + 3) / 4), Nk);
 }
 
 int check_common(const void *q, const void *k, const void *v, const void *o, int B, int H, int Nq, int Nk) {
@@ -957,8 +971,7 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
         rc = launch_attn<false, false, true>(p, st);
     }
     if (rc != CHIPMUNK_OK) return rc;
-    // second pass: one wave per 192-row group for long launches (attn64.hip; option attn_colsum64: 1 = always, 2 = never)
-    const int oc = chipmunk_get_option("attn_colsum64");
-    if (Nk >= 64 && (oc == 1 || (oc == 0 && use_dense64(B, H, Nq, Nk)))) return chipmunk_colsum64_launch(p, st);
+    // second pass: one wave per 192-row group where that fills the CUs (attn64.hip), the general kernel's K-only pass otherwise
+    if (use_colsum64(B, H, Nq, Nk)) return chipmunk_colsum64_launch(p, st);
     return launch_attn<false, false, false, true>(p, st);
 }
