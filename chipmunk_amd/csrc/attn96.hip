@@ -311,10 +311,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (qb == 2) {
                     if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
                     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
-                } else {   // (lgkmcnt(6): the K fragment re-read / the window fragment has at least six younger reads behind it)
+                } else {
+                    // LDS reads return in order: a wait states how many of the youngest may still be in flight.  Block 0 waits
+                    // twice for its K fragments (re-read at slots 33..47 of the previous tile), block 1 four times for its window
+                    // (fragment ks read at slot 9 + 2 ks); the counts are the reads issued since, slot by slot.
+                    constexpr int WAIT = qb == 0 ? (ks == 0 ? 12 : ks == 4 ? 8 : -1) : (ks == 6 ? 4 : (ks & 1) == 0 ? 6 : -1);
                     const u32x4 &qf = qb == 0 ? qv[ks] : q1w[ks & 3];
-                    if constexpr (ks == 0) asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
-                    else asm volatile("s_waitcnt lgkmcnt(6)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
+                    if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(WAIT) : "memory");
+                    if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
                 }
                 if constexpr (SG % 4 == 2 && SG < 32) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2)
                     constexpr int PC = (SG - 2) / 4;
@@ -323,8 +328,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             } else {                         // ---- PV
                 constexpr int I = (SG - 1) / 2, J = (I + 21) % 24, qbp = J / 8, up = (J % 8) / 4, db = J % 4, oa = (qbp * 4 + db) * 16;
-                asm volatile("s_waitcnt lgkmcnt(4)\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
-                             ::"v"(vfw[J & 3]), "v"(pw[qbp][up]), "i"(oa), "i"(oa + 15));
+                // every other element waits, for its own fragment and the next one's: all but the previous slot's reads (two for the
+                // V^T fragment, one more where that slot also re-read a K fragment or a window fragment) have landed
+                if constexpr ((I & 1) == 0) {
+                    constexpr int PS = SG - 2, EXTRA = ((PS >= 9 && PS <= 23) || PS >= 33 || PS < 0) ? 1 : 0;   // (PS < 0: slot 47 of the tile before)
+                    asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(2 + EXTRA) : "memory");
+                }
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vfw[J & 3]), "v"(pw[qbp][up]), "i"(oa), "i"(oa + 15));
                 vfrag_read(ic<(I % 4)>{}, ic<VSL * TB + ((I % 8) / 4) * 4096>{}, vfw[I & 3]);   // fragment I of V(t-1): d block I%4, slab (I%8)/4
                 if constexpr (SG >= 9 && SG <= 23) q1_read(ic<(SG - 9) / 2>{}, q1w[((SG - 9) / 2) & 3]);
                 if constexpr (SG >= 33) lds_k<(SG - 33) / 2, KNSL>(kad[(SG - 33) / 2]);
