@@ -751,8 +751,12 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // loader wave per 192-row group, ONE workgroup per CU).  Off by default: at equal counts it measured +2.7 % (random
     // keys) / +5.4 % (keys shared between groups) over this file's kernel, but on HunyuanVideo's ragged launches (text /
     // tail groups 13x longer than the rest, one workgroup per CU) 15.5 vs 14.3 ms.
-    const int o96 = chipmunk_get_option("attn_csp96");   // 1: the two-waves-x-96-rows kernel of attn96.hip (plan as below)
-    const bool want96 = GATHER && !CSONLY && !WRITE_L && o96 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
+    // Gathered launches with at least three rounds of long items go to the two-waves-x-96-rows kernel of attn96.hip (same
+    // plan, same scratch): HunyuanVideo 24 heads +2 %, a head-parallel rank's 3 heads +6 %; short items (FLUX: 21 tiles) and
+    // single heads stay here (its per-item prologue and epilogue are longer).  Option attn_csp96: 1 = always, 2 = never.
+    const int o96 = chipmunk_get_option("attn_csp96");
+    const bool fits96 = GATHER && !CSONLY && !WRITE_L && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
+    const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 6 * (int64_t)device_cu_count() && p.Nk >= 32768));
     const int o64 = chipmunk_get_option("attn_csp64");
     const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
