@@ -30,6 +30,11 @@ constexpr int QLDS = 2 * NSL * TB;        // byte offset of the Q^T block 1 stag
 constexpr int LDS_BYTES = QLDS + 2 * 8192;   // 80 KiB: two workgroups per CU = all 160 KiB
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
+// timing ablations (results wrong; read SQ_WAVE_CYCLES, not the clock): 1 = no softmax pipelines, 2 = no V^T reads,
+// 4 = no DMA / vmcnt / barrier, 8 = no K re-reads and no Q window reads
+#ifndef A96_ABL
+#define A96_ABL 0
+#endif
 
 // S^T block qb (+)= K fragment ks . Q^T fragment (qb, ks); Q^T of blocks 0 and 1 in VGPRs, of block 2 in a[224:255]
 template <int QB, int KS>
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 7; ++r) s[1][r] = 0.f;   // (block 1's first seven elements are past the exp2 stage at the tile seam: p = 0)
     u32x4 pw[3][2] = {};         // P^T fragments (block, key slab)
     u32x4 vfw[4] = {};           // V^T fragment window (zero: the first PV elements multiply P = 0 by it)
-    u32x4 q1w[4];                // Q^T block-1 window
+    u32x4 q1w[4] = {};           // Q^T block-1 window
     float m[3] = {-INFINITY, -INFINITY, -INFINITY}, nmsc[3] = {0.f, 0.f, 0.f}, mlag[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lacc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     int vl_prev = KT;            // packed positions that exist in the previous tile (its block 2 is masked in this one)
@@ -296,11 +301,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago; an iteration is 8 pieces + 1 (4) index loads
-        if (idx_vec) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(A96_ABL & 4)) {
+            if (idx_vec) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         P96_MARK(0);
-        ir[(SL + 1) & 3] = load_idx(t + 5);
+        if constexpr (!(A96_ABL & 4)) ir[(SL + 1) & 3] = load_idx(t + 5);
         const int vl_cur = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist
         float mxa, mxb, mxc;   // block maxima: this tile's block 0, this tile's block 1, the previous tile's block 2
         __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
                     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
                 }
-                if constexpr (SG % 4 == 2 && SG < 32) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2)
+                if constexpr (SG % 4 == 2 && SG < 32 && !(A96_ABL & 4)) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2)
                     constexpr int PC = (SG - 2) / 4;
                     if constexpr (PC < 4) issue_k1(ir[SL], SL, PC);
                     else issue_v1(ir[(SL + 2) & 3], (SL + 2) & 3, PC - 4);
@@ -335,11 +342,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(2 + EXTRA) : "memory");
                 }
                 asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vfw[J & 3]), "v"(pw[qbp][up]), "i"(oa), "i"(oa + 15));
-                vfrag_read(ic<(I % 4)>{}, ic<VSL * TB + ((I % 8) / 4) * 4096>{}, vfw[I & 3]);   // fragment I of V(t-1): d block I%4, slab (I%8)/4
-                if constexpr (SG >= 9 && SG <= 23) q1_read(ic<(SG - 9) / 2>{}, q1w[((SG - 9) / 2) & 3]);
-                if constexpr (SG >= 33) lds_k<(SG - 33) / 2, KNSL>(kad[(SG - 33) / 2]);
+                if constexpr (!(A96_ABL & 2)) vfrag_read(ic<(I % 4)>{}, ic<VSL * TB + ((I % 8) / 4) * 4096>{}, vfw[I & 3]);   // fragment I of V(t-1): d block I%4, slab (I%8)/4
+                if constexpr (SG >= 9 && SG <= 23 && !(A96_ABL & 8)) q1_read(ic<(SG - 9) / 2>{}, q1w[((SG - 9) / 2) & 3]);
+                if constexpr (SG >= 33 && !(A96_ABL & 8)) lds_k<(SG - 33) / 2, KNSL>(kad[(SG - 33) / 2]);
             }
             // ---- the three softmax pipelines
+            if constexpr (!(A96_ABL & 1)) {
             if constexpr (SG == 0) mask_block(s[2], vl_prev);                       // block 2 of tile t-1
             if constexpr (SG >= 1 && SG <= 4) max_step(ic<SG - 1>{}, s[2], mxc);
             if constexpr (SG == 5) max_halves(mxc);
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (SG == 37) max_halves(mxb);
             if constexpr (SG == 39) update_block(ic<1>{}, mxb);
             if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         vl_prev = vl_cur;
