@@ -36,7 +36,7 @@ def one_pass(counter, what, extra_env=None):
 
 
 C3_KERNELS = {  # HunyuanVideo shapes (bench.py workload hunyuan_c3): kbench cases with all 24 heads
-    "csp_128_attn_c3": "attn_kernel<true, true", "dense_attn_c3": "attn64_kernel<0>",   # long dense launches: attn64.hip
+    "csp_128_attn_c3": "csp96_kernel<true>", "dense_attn_c3": "attn64_kernel<0>",   # long launches: attn96.hip / attn64.hip
     "colsum_pass_c3": "colsum64_kernel",
 }
 
