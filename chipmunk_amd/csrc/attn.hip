@@ -740,11 +740,10 @@ template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
 int launch_attn(const AttnParams &p, hipStream_t stream) {
     auto kern = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY>;
     const int LDS = chipmunk_get_option("attn_pp") == 1 ? 96 * 1024 : ATTN_LDS_BYTES - (CSONLY ? NSTV * TILE_BYTES : 0);
-    static int attr_set = 0;
-    if (attr_set != LDS) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = LDS;
-    }
+    static uint64_t lds_set = 0;
+    static int lds_bytes = 0;
+    if (lds_bytes != LDS) lds_set = 0, lds_bytes = LDS;   // (the attn_pp experiment knob changes the request)
+    ensure_dynamic_lds((const void *)kern, LDS, lds_set);
     const int64_t nblocks = (int64_t)p.B * p.H * p.G;
     if (nblocks == 0) return CHIPMUNK_OK;
     // option attn_csp64 = 1 sends gathered launches to the one-wave-per-SIMD kernel (attn64.hip: three compute waves + a

@@ -774,11 +774,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int MODE>
 int launch64(const AttnParams &p, int64_t grid, hipStream_t stream) {
     auto kern = attn64_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)kern, LDS_BYTES, lds_set);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
@@ -807,11 +804,8 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
 
 // column-sum pass of dense_colsum_attn, one wave per 192-row group (p.p_in, p.cs, p.cs_stride, p.G = groups of 192)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)colsum64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSL * TB);
-        attr_set = true;
-    }
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)colsum64_kernel, NSL * TB, lds_set);
     const int64_t grid = (int64_t)p.B * p.H * ((p.G + 3) / 4);
     hipLaunchKernelGGL(colsum64_kernel, dim3((unsigned)grid), dim3(256), NSL * TB, stream, p);
     CM_LAUNCH_CHECK();

@@ -491,11 +491,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <bool INPLACE>
 int launch96(const AttnParams &p, int grid, hipStream_t stream) {
     auto kern = csp96_kernel<INPLACE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)kern, LDS_BYTES, lds_set);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128), LDS_BYTES, stream, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;

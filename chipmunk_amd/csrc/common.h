@@ -139,6 +139,17 @@ inline int device_cu_count() {
     return n;
 }
 
+// Dynamic LDS above 64 KiB has to be requested per kernel AND per device; `done` is the caller's static per-kernel bit set
+// (bit = device ordinal), so a process that drives several devices asks once on each.
+inline void ensure_dynamic_lds(const void *kernel, int bytes, uint64_t &done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (!(done >> dev & 1)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done |= uint64_t(1) << dev;
+    }
+}
+
 // ---- host-side error plumbing (thread-local message, see chipmunk_last_error) ----
 void chipmunk_set_error(const char *fmt, ...);
 int chipmunk_get_option(const char *name);

@@ -679,11 +679,8 @@ template <int BN, int BK, int NST, int WPS, int NW = 4>
 int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
     constexpr int LDS = NST * (BM * BK * 2 + BK * BN * 2);
     auto kern = mm2_kernel<BN, BK, NST, WPS, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)kern, LDS, lds_set);
     Mm2Params p = p0;
     p.NT = (p.N2 + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm2_nr") > 0 ? chipmunk_get_option("mm2_nr") : 4;
@@ -723,11 +720,8 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated =
     constexpr int LDS = NST * (BM * BK * 2 + BN * BK * 2);
     constexpr bool STAGED = BM * BN * 2 <= (BM + BN) * BK * 2;  // mm1_tile's staged epilogue (the one that can scatter)
     auto kern = mm1_kernel<BN, BK, NST, WPS, FP8>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)kern, LDS, lds_set);
     Mm1Params p = p0;
     if (!STAGED) p.update_cache = 0;
     if (cache_updated) *cache_updated = p.update_cache != 0;
