@@ -3,14 +3,14 @@
 // rows, two workgroups per CU.  (attn64.hip's 64-row waves leave a quarter of the CU idle on 192-row groups; the
 // general kernel of attn.hip puts two 48-row waves on every SIMD and is bound by the issue slots they share.)
 //   * per wave: O^T (96 x 128 f32) in a[0:191], the eight K fragments of the 32-key tile in a[192:223], the Q^T
-//     fragments of the third 32-row block in a[224:255] (the other two blocks' in 64 VGPRs) -- accumulator registers
-//     are only ever named from inline asm (same audit rule as attn64.hip);
+//     fragments of the third 32-row block in a[224:255], of the first in 32 VGPRs, of the second staged in LDS and
+//     streamed through a 4-fragment window (64 VGPRs of Q beside the softmax made hipcc spill into the accumulator
+//     file) -- accumulator registers are only ever named from inline asm (same audit rule as attn64.hip);
 //   * swapped layout S^T = K.Q^T on v_mfma_f32_32x32x16_bf16: a lane owns a query column, softmax statistics are
 //     lane-local, the bf16 P^T feeds O^T += V^T.P^T from registers;
-//   * per 32-key tile two phases of 24 MFMAs: A(t) = S(t) = K(t).Q^T beside the V^T(t-1) fragment reads and the DMA
-//     issue; B(t) = O += V(t-1).P(t-1) beside the whole softmax of tile t, done IN PLACE on the score registers (a
-//     second score buffer does not fit beside 64 VGPRs of Q), and the K(t+1) fragment reads.  Phase B is VALU-bound
-//     (~200 VALU issues for 24 MFMAs), phase A runs at the MFMA rate;
+//   * per 32-key tile ONE stream of 48 MFMAs, QK^T and PV alternating, query block by query block; the softmax of a
+//     block runs IN PLACE on its score registers as a 31-slot pipeline while the other blocks' MFMAs issue, the three
+//     pipelines staggered by 16 slots (see the main loop's comment);
 //   * gather: each wave stages half of every K and V tile by LDS-DMA (4 + 4 pieces); LDS row 4*pc + lg of a tile holds
 //     packed position (pc >> 2)*16 + lg*4 + (pc & 3), so a lane group reads 4 consecutive indices per tile and piece i
 //     takes register i; index registers of four tiles in a ring; one s_barrier (two waves) + one counted vmcnt per tile;
@@ -36,18 +36,7 @@ constexpr float MAX_LAG = 4.0f;
 #define A96_ABL 0
 #endif
 
-// S^T block qb (+)= K fragment ks . Q^T fragment (qb, ks); Q^T of blocks 0 and 1 in VGPRs, of block 2 in a[224:255]
-template <int QB, int KS>
-__device__ __forceinline__ void mfma_qk(f32x16 &s, const u32x4 &qv) {
-    constexpr int ka = 192 + KS * 4, qa = 224 + KS * 4;
-    if constexpr (QB < 2) {
-        if constexpr (KS == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s) : "i"(ka), "i"(ka + 3), "v"(qv));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s) : "i"(ka), "i"(ka + 3), "v"(qv));
-    } else {
-        if constexpr (KS == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
-    }
-}
+// O^T block (qb, db) += V^T fragment . P^T fragment (the drain after the loop; the loop issues its MFMAs in place)
 template <int QB, int DB>
 __device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &pf) {
     constexpr int oa = (QB * 4 + DB) * 16;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Cycle anatomy of the attn96.hip main loop: builds the library with -DATTN96_PROF into tools/bin/libchipmunk_a96prof.so
-and prints cycles per 32-key tile per segment for both waves of workgroup 700: wait+barrier | phase A (24 QK MFMAs) |
-V-fragment wait | phase B gaps 0-7 | reference check | phase B gaps 8-23 + tail | rescale + K/Q-window wait."""
+and prints cycles per 32-key tile for both waves of workgroup 700: the counted wait + barrier at the top of a tile | its 48
+MFMA slots (finer splits cost more than they tell: every s_memtime read drains the LDS queue)."""
 import ctypes
 import os
 import subprocess
@@ -37,8 +37,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 assert lib.chipmunk_attn96_prof_read(buf) == 0
-names = ["wait+bar", "phaseA", "vf wait", "B 0-7", "check", "B 8-23", "tail"]
+names = ["wait+bar", "48 slots"]
 for w in range(2):
     n = buf[w * 8 + 7]
-    per = [buf[w * 8 + i] / max(n, 1) for i in range(7)]
+    per = [buf[w * 8 + i] / max(n, 1) for i in range(2)]
     print(f"wave {w}: tiles {n}  " + "  ".join(f"{nm} {x:7.1f}" for nm, x in zip(names, per)) + f"   total {sum(per):7.1f}")
