@@ -52,7 +52,9 @@ def parse_args():
     ap.add_argument("--top-keys", type=float, default=None, help="hunyuan: attn.top_keys override (0.17 ~ 82 %% sparsity)")
     ap.add_argument("--no-82", action="store_true", help="hunyuan: skip the 82 %% sparsity leg")
     ap.add_argument("--offload", action="store_true", help="hunyuan: caches through pinned host memory (keep_resident_if_fits off)")
-    ap.add_argument("--sp-chunk-heads", type=int, default=1, help="hunyuan_sp: local heads per pipeline chunk")
+    ap.add_argument("--sp-chunk-heads", type=int, default=0,
+                    help="hunyuan_sp: local heads per pipeline chunk (0 = 3 when a rank has at least 6 heads -- a 3-head launch runs the "
+                         "gathered kernel 20 %% more efficiently than three 1-head ones and still leaves >= 2 chunks to overlap -- else 1)")
     ap.add_argument("--sp-no-overlap", action="store_true", help="hunyuan_sp: exchange on the compute stream (reference order)")
     ap.add_argument("--sp-no-exchange", action="store_true", help="hunyuan_sp: compute only (probe for the exposed-comm fraction)")
     ap.add_argument("--grid", default="33,45,80", help="hunyuan: latent patch grid T,H,W (default 720x1280x129)")
@@ -312,6 +314,8 @@ class Hunyuan:
         self.n_layers = args.layers or 60
         assert self.H % world == 0 and self.n_img % world == 0, "head-parallel sharding needs world | 24 and world | tokens"
         self.lh, self.ls = self.H // world, self.n_img // world
+        if args.sp_chunk_heads <= 0:
+            args.sp_chunk_heads = 3 if (self.lh >= 6 and self.lh % 3 == 0) else 2 if (self.lh >= 4 and self.lh % 2 == 0) else 1
         H, D, N = self.H, self.D, self.N
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         bf = dict(device=dev, dtype=torch.bfloat16)
