@@ -187,3 +187,35 @@ def test_colsum64_vs_oracle(dev, n, nk):
     torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
     assert_close_bf16(cs[..., :nk], cs_ref[..., :nk], atol=2e-3, rtol=3e-2, what="colsum64 cs vs oracle")
     assert torch.equal(cs[..., :nk], again[..., :nk]), "no order-dependent reduction: run-to-run identical"
+
+
+@pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
+def test_csp64_running_max_update_paths(dev, forced_csp, pattern):
+    """the gathered one-wave-per-SIMD kernels on the constructions that force the reference point of the exponentials to
+    move (per query block, with the rescale of that block's accumulator registers) for some lanes and not for others"""
+    import math
+    n, H = 1152, 2
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, H, n, 128, generator=g)
+    k = torch.randn(1, H, n, 128, generator=g)
+    v = torch.randn(1, H, n, 128, generator=g)
+    u = torch.randn(128, generator=g)
+    u = u / u.norm()
+    q = 0.3 * q + 3.0 * u
+    if pattern == "ramp":
+        k = 0.3 * k + (torch.arange(n).float() / n * 30.0)[None, None, :, None] * u
+    elif pattern == "descending":
+        k = 0.3 * k + ((n - torch.arange(n)).float() / n * 30.0)[None, None, :, None] * u
+    else:
+        k = 0.3 * k
+        j = 5 if pattern == "spike_first" else 1000
+        k[0, :, j] += 40.0 * u
+        q[0, :, ::3] *= 0.05
+    q, k, v = [t.to(torch.bfloat16) for t in (q, k, v)]
+    o_ref, _ = oracle.dense_attn(q, k, v)
+    G = math.ceil(n / 192)
+    counts = torch.full((1, H, G), n, dtype=torch.int32)
+    for name, order in (("identity", torch.arange(n)), ("reverse", torch.arange(n - 1, -1, -1))):
+        inds = order.to(torch.int32).expand(1, H, G, n).contiguous()
+        o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+        assert_close_bf16(o, o_ref, what=f"gathered, {name} key order, {pattern}")
