@@ -100,7 +100,8 @@ def forced_csp(dev, request):
     _native.set_option(request.param, 0)
 
 
-@pytest.mark.parametrize("n,nk,count", [(384, 384, 128), (1000, 1000, 333), (1152, 1152, 1152), (576, 2000, 64), (200, 640, 7), (960, 960, 0)])
+@pytest.mark.parametrize("n,nk,count", [(384, 384, 128), (1000, 1000, 333), (1152, 1152, 1152), (576, 2000, 64), (200, 640, 7), (960, 960, 0),
+                                         (576, 997, 333), (390, 1001, 1001)])   # (index rows that are not 16-byte aligned: the dword load path)
 def test_csp64_random_indices_vs_oracle(dev, forced_csp, n, nk, count):
     """csp_128_attn: ragged query groups, counts that are not multiples of the 64-key tile (masked tail), fewer keys than a
     tile, all keys, no keys"""
