@@ -167,7 +167,7 @@ def sorted_random_indices(H, G, n_keys, count, width, g):
 def bench_attn(which, variants):
     g = torch.Generator(device=dev).manual_seed(0)
     if "hunyuan" in which:
-        H, N, count = int(os.environ.get('KB_HEADS', '6')), 119056, int(os.environ.get('KB_COUNT_C3', '7296'))   # BASELINE C3 counts; KB_HEADS=24 for all heads
+        H, N, count = int(os.environ.get('KB_HEADS', '6')), int(os.environ.get('KB_N', '119056')), int(os.environ.get('KB_COUNT_C3', '7296'))   # BASELINE C3 counts; KB_HEADS=24 for all heads
     else:
         H, N, count = 24, 4352, int(os.environ.get('KB_COUNT', '672'))
     q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
