@@ -92,6 +92,36 @@ __device__ __forceinline__ void lds_k(uint32_t addr) {
     constexpr int ka = 192 + (KB * 8 + KS) * 4;
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(ka), "i"(ka + 3), "i"(SLOT * TB + KB * 8192) : "memory");
 }
+// Largest row norm of K per (batch, head): one 16-lane group per row (a lane squares its 8 elements, DPP row sum), maximum
+// over the block, one atomicMax on the float's bits (non-negative floats order like unsigned integers; the buffer is
+// zeroed by a memset node before every launch).  730 MB of K at HunyuanVideo size: ~0.2 ms beside a 130 ms launch.
+__global__ __launch_bounds__(256) void knorm_max_kernel(const uint16_t *k, const int64_t ks0, const int64_t ks1, const int64_t ks2, int H, int Nk,
+                                                        float *out) {
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const uint16_t *kb = k + b * ks0 + h * ks1;
+    const int grp = threadIdx.x >> 4, li = threadIdx.x & 15;
+    float best = 0.f;
+    for (int row = blockIdx.x * 16 + grp; row < Nk; row += gridDim.x * 16) {
+        const u32x4 v = *(const u32x4 *)(kb + (int64_t)row * ks2 + li * 8);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+            ss = __builtin_fmaf(lo, lo, ss);
+            ss = __builtin_fmaf(hi, hi, ss);
+        }
+        best = fmaxf(best, row16_sum(ss));
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax((unsigned int *)(out + bh), __float_as_uint(__builtin_sqrtf(red[0])));
+}
+
 // MODE 0: dense -- 256-row workgroups, every wave computes 64 rows and stages its quarter of each tile.
 // MODE 1 / 2: gathered (csp_128_attn / the accumulate forms csp_attn, csp_attn_out) -- one 192-row query group per
 //   workgroup: waves 0..2 compute 64 rows each, wave 3 is the LOADER: it reads the group's index list, forms the per-lane
@@ -213,6 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- accumulator file: O^T = 0, Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7)
     asm volatile(A64_ZERO_O ::: A64_CLOBBER_ALL);
+    float qss[2] = {0.f, 0.f};   // this lane's half of |q|^2 per query block
     {
         const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1];
         static_for<0, 16>([&](auto f) {
@@ -221,6 +252,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             u32x4 val = {0u, 0u, 0u, 0u};
             if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
             acc_write4<128 + F * 4>(val);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
+                qss[qb] = __builtin_fmaf(lo, lo, qss[qb]);
+                qss[qb] = __builtin_fmaf(hi, hi, qss[qb]);
+            }
         });
     }
 
@@ -341,8 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     P64_DECL;
     P64_START();
     // one tile: ring slot SL = t mod 4 (static), K(t) already in a[192:255]
-    auto tile = [&](auto slc, int t) __attribute__((always_inline)) {
+    auto tile = [&](auto slc, auto nmc, int t) __attribute__((always_inline)) {
         constexpr int SL = decltype(slc)::value;
+        constexpr bool NOMAX = decltype(nmc)::value != 0;   // fixed reference point (see below): no maxima, no update, no rescale
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago: the issues of the last two iterations may stay in flight
@@ -431,7 +469,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             if ((r & 3) * 16 + (blk >> 1) * 8 + 2 * (r >> 2) >= thr) s[blk][r] = -INFINITY;
                 }
             }
-            if constexpr (G >= 2 && G <= 9 && !(A64_ABL & 2)) {   // maxima of the 32 scores a lane holds per query block: 16 x v_max3 each, two per
+            if constexpr (G >= 2 && G <= 9 && !(A64_ABL & 2) && !NOMAX) {   // maxima of the 32 scores a lane holds per query block: 16 x v_max3 each, two per
                 constexpr int j = G - 2;        // block per gap, the four of a gap in one statement (one boundary pad, not four)
                 constexpr int kb2 = j >> 2, r0 = (j & 3) * 4;
                 if constexpr (j == 0)
@@ -444,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                              : "v"(s[kb2 * 2][r0]), "v"(s[kb2 * 2][r0 + 1]), "v"(s[kb2 * 2][r0 + 2]), "v"(s[kb2 * 2][r0 + 3]),
                                "v"(s[kb2 * 2 + 1][r0]), "v"(s[kb2 * 2 + 1][r0 + 1]), "v"(s[kb2 * 2 + 1][r0 + 2]), "v"(s[kb2 * 2 + 1][r0 + 3]));
             }
-            if constexpr (G == 10 && !(A64_ABL & 2)) {  // the other half of the keys lives in lane ^ 32
+            if constexpr (G == 10 && !(A64_ABL & 2) && !NOMAX) {  // the other half of the keys lives in lane ^ 32
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
                     float a = mx[q2], c = mx[q2];
@@ -466,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         static_for<0, 12>(phase_b_gap);
         P64_MARK(3);
-        if constexpr (!(A64_ABL & 2)) {   // the (rare) move of the reference point
+        if constexpr (!(A64_ABL & 2) && !NOMAX) {   // the (rare) move of the reference point
             constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
             if (__builtin_amdgcn_ballot_w64(mx[0] > mlag[0]) | __builtin_amdgcn_ballot_w64(mx[1] > mlag[1])) {
                 moved = true;
@@ -498,12 +536,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // tiles 0 .. T4-1 (multiples of four: the padding tiles are fully masked), then one more pass whose phase A finishes
     // tile T4-1 and whose phase B accumulates it (its own -- masked -- tile is never finished)
-    for (int tb = 0;; tb += 4) {
-        tile(ic<0>{}, tb);
-        if (tb >= T4) break;
-        tile(ic<1>{}, tb + 1);
-        tile(ic<2>{}, tb + 2);
-        tile(ic<3>{}, tb + 3);
+    // Fixed reference point.  |s_ij| <= |q_i| * max_j |k_j| =: M_i (Cauchy-Schwarz; kmax from knorm_max_kernel).  With the
+    // exponentials taken against M_i from the first tile on, p = exp2((s - M) c) lies in [2^(-2 M c), 1]: if 2 M c <= 64 for
+    // every query of the wave that is inside the normal range of fp32 and bf16, the softmax is the same up to rounding
+    // (floating point is scale invariant; o = acc / l and l_out = 1 / (2^(M c) l) do not care which reference was used),
+    // and the 32 v_max3, the lane-half exchange, the check and the rescale path leave the loop (46 of ~350 issues per
+    // tile).  Unit-variance q, k at HunyuanVideo size: 2 M c ~ 42.  Waves that cannot prove the bound (large-norm inputs)
+    // run the running-maximum loop; the choice is per wave and changes nothing but rounding.
+    bool nomax = false;
+    if constexpr (!GATHER) {
+        if (p.kmax) {
+            const float km = p.kmax[bh];
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float a = qss[qb], c2 = qss[qb];
+                lane_swap32(a, c2);
+                const float mq = __builtin_sqrtf(a + c2) * km;   // M_i in raw score units
+                ok = ok && (2.0f * mq * SCALE_LOG2E <= 64.0f);
+                qss[qb] = mq;
+            }
+            nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
+            if (nomax) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) m[qb] = qss[qb], nmsc[qb] = -qss[qb] * SCALE_LOG2E, mlag[qb] = INFINITY;
+            }
+        }
+    }
+    if (nomax) {
+        for (int tb = 0;; tb += 4) {
+            tile(ic<0>{}, ic<1>{}, tb);
+            if (tb >= T4) break;
+            tile(ic<1>{}, ic<1>{}, tb + 1);
+            tile(ic<2>{}, ic<1>{}, tb + 2);
+            tile(ic<3>{}, ic<1>{}, tb + 3);
+        }
+    } else {
+        for (int tb = 0;; tb += 4) {
+            tile(ic<0>{}, ic<0>{}, tb);
+            if (tb >= T4) break;
+            tile(ic<1>{}, ic<0>{}, tb + 1);
+            tile(ic<2>{}, ic<0>{}, tb + 2);
+            tile(ic<3>{}, ic<0>{}, tb + 3);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P64_END(w, T4 + 1);
@@ -799,6 +874,18 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + WGROWS - 1) / WGROWS;
     p.o_scale = 1.f;
+    if (chipmunk_get_option("attn_nomax") != 2) {   // 2 = always the running-maximum loop (A/B, tests)
+        // the largest K row norm per (batch, head), into the library scratch behind the tickets (attn.hip's layout)
+        unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, (64 << 10) + (size_t)B * H * sizeof(float));
+        if (sc) {
+            float *km = (float *)(sc + (64 << 10));
+            if (hipMemsetAsync(km, 0, (size_t)B * H * sizeof(float), stream) == hipSuccess) {
+                const int chunks = Nk >= 16384 ? 64 : 8;
+                hipLaunchKernelGGL(knorm_max_kernel, dim3(chunks, B * H), dim3(256), 0, stream, p.k, ks[0], ks[1], ks[2], H, Nk, km);
+                p.kmax = km;
+            }
+        }
+    }
     return launch64<0>(p, (int64_t)B * H * p.G, stream);
 }
 

@@ -25,6 +25,10 @@ struct AttnParams {
     // (plan[2i+1] & 0xffff) of (plan[2i+1] >> 16) slices over the item's key tiles; slices of one item are adjacent
     const int32_t *plan;
     int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
+    // attn64.hip / attn96.hip: per (batch, head) the largest Euclidean norm of a K row (knorm_max_kernel), or nullptr.  With it
+    // a wave can prove |s_ij| <= |q_i| * kmax for all its queries; if that bound is small enough for the exponent range, the
+    // exponentials are taken against the FIXED reference point |q_i| * kmax and the running-maximum work disappears.
+    const float *kmax;
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 

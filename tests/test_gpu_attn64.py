@@ -220,3 +220,28 @@ def test_csp64_running_max_update_paths(dev, forced_csp, pattern):
         inds = order.to(torch.int32).expand(1, H, G, n).contiguous()
         o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
         assert_close_bf16(o, o_ref, what=f"gathered, {name} key order, {pattern}")
+
+
+@pytest.mark.parametrize("scale,expect", [(1.0, "fixed"), (4.0, "running")])
+def test_dense64_fixed_reference_point_and_its_fallback(dev, forced, scale, expect):
+    """unit-variance inputs let every wave prove |s| <= |q| max|k| small enough: the exponentials use that fixed reference
+    point and no running maximum; 4x larger inputs (scores 16x) cannot, and run the running-maximum loop.  Same results
+    (o, l) within the stated tolerances either way, and the same as with the fixed reference switched off."""
+    from chipmunk_amd import _native
+    n = 1536
+    q = (randn_bf16(1, 2, n, 128, seed=21).float() * scale).to(torch.bfloat16)
+    k = (randn_bf16(1, 2, n, 128, seed=22).float() * scale).to(torch.bfloat16)
+    v = randn_bf16(1, 2, n, 128, seed=23)
+    o_ref, l_ref = oracle.dense_attn(q, k, v)
+    o, l = torch.ops.chipmunk.dense_attn(q.to(dev), k.to(dev), v.to(dev))
+    assert_close_bf16(o, o_ref, what=f"dense64 ({expect} reference)")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    _native.set_option("attn_nomax", 2)
+    try:
+        o2, l2 = torch.ops.chipmunk.dense_attn(q.to(dev), k.to(dev), v.to(dev))
+    finally:
+        _native.set_option("attn_nomax", 0)
+    assert_close_bf16(o2, o_ref, what="dense64, running maximum forced")
+    torch.testing.assert_close(l2.cpu(), l_ref, rtol=1e-3, atol=0)
+    if expect == "running":
+        assert torch.equal(o, o2) and torch.equal(l, l2), "inputs too large for the bound: both runs take the running-maximum loop"
