@@ -864,6 +864,19 @@ extern "C" int chipmunk_attn64_prof_read(unsigned long long *out) {
 }
 #endif
 
+// The largest K row norm per (batch, head) for the fixed reference point of attn64 / attn96 (nullptr: not available, the
+// kernels then keep a running maximum).  Lives in the second half of the library scratch's 64 KiB ticket region (the tickets
+// of attn.hip's hand-offs use the first few KiB); option attn_nomax = 2 switches it off (A/B, tests).
+const float *chipmunk_knorm_max(const uint16_t *k, const int64_t ks[3], int B, int H, int Nk, hipStream_t stream) {
+    if (chipmunk_get_option("attn_nomax") == 2 || (size_t)B * H * sizeof(float) > (32 << 10)) return nullptr;
+    unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, 64 << 10);
+    if (!sc) return nullptr;
+    float *km = (float *)(sc + (32 << 10));
+    if (hipMemsetAsync(km, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(knorm_max_kernel, dim3(Nk >= 16384 ? 64 : 8, B * H), dim3(256), 0, stream, k, ks[0], ks[1], ks[2], H, Nk, km);
+    return km;
+}
+
 // dense attention through the one-wave-per-SIMD kernel (strides in elements, [batch, head, row])
 int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o, float *l, const int64_t qs[3],
                             const int64_t ks[3], const int64_t vs[3], const int64_t os[3], int B, int H, int Nq, int Nk,
@@ -874,18 +887,7 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + WGROWS - 1) / WGROWS;
     p.o_scale = 1.f;
-    if (chipmunk_get_option("attn_nomax") != 2) {   // 2 = always the running-maximum loop (A/B, tests)
-        // the largest K row norm per (batch, head), into the library scratch behind the tickets (attn.hip's layout)
-        unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, (64 << 10) + (size_t)B * H * sizeof(float));
-        if (sc) {
-            float *km = (float *)(sc + (64 << 10));
-            if (hipMemsetAsync(km, 0, (size_t)B * H * sizeof(float), stream) == hipSuccess) {
-                const int chunks = Nk >= 16384 ? 64 : 8;
-                hipLaunchKernelGGL(knorm_max_kernel, dim3(chunks, B * H), dim3(256), 0, stream, p.k, ks[0], ks[1], ks[2], H, Nk, km);
-                p.kmax = km;
-            }
-        }
-    }
+    p.kmax = chipmunk_knorm_max(p.k, ks, B, H, Nk, stream);
     return launch64<0>(p, (int64_t)B * H * p.G, stream);
 }
 

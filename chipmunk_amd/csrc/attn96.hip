@@ -97,6 +97,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // block 0 in 32 VGPRs, block 2 in a[224:255], block 1 staged in LDS (its 32 registers do not fit beside the softmax) and
     // streamed through a two-fragment window, one ds_read_b128 per k step and tile
     u32x4 qv[8];
+    float qss[3] = {0.f, 0.f, 0.f};   // this lane's half of |q|^2 per query block (fixed reference point, see the loop selection)
     {
         const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1];
         static_for<0, 24>([&](auto f) {
@@ -104,6 +105,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int qrow = row0 + qb * 32 + l31;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
+                qss[qb] = __builtin_fmaf(lo, lo, qss[qb]);
+                qss[qb] = __builtin_fmaf(hi, hi, qss[qb]);
+            }
             if constexpr (qb == 0) qv[ks] = val;
             else if constexpr (qb == 2) acc_write4<224 + ks * 4>(val);
             else *(u32x4 *)(smem + QLDS + w * 8192 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4)) = val;   // (own wave's rows only)
@@ -285,8 +292,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     P96_DECL;
     P96_START();
-    auto tile = [&](auto slc, int t) __attribute__((always_inline)) {
+    auto tile = [&](auto slc, auto nmc, int t) __attribute__((always_inline)) {
         constexpr int SL = decltype(slc)::value;
+        constexpr bool NOMAX = decltype(nmc)::value != 0;   // fixed reference point: no maxima, no update / rescale
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago; an iteration is 8 pieces + 1 (4) index loads
@@ -338,20 +346,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // ---- the three softmax pipelines
             if constexpr (!(A96_ABL & 1)) {
             if constexpr (SG == 0) mask_block(s[2], vl_prev);                       // block 2 of tile t-1
-            if constexpr (SG >= 1 && SG <= 4) max_step(ic<SG - 1>{}, s[2], mxc);
-            if constexpr (SG == 5) max_halves(mxc);
-            if constexpr (SG == 7) update_block(ic<2>{}, mxc);
+            if constexpr (SG >= 1 && SG <= 4 && !NOMAX) max_step(ic<SG - 1>{}, s[2], mxc);
+            if constexpr (SG == 5 && !NOMAX) max_halves(mxc);
+            if constexpr (SG == 7 && !NOMAX) update_block(ic<2>{}, mxc);
             if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{});
             if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{});                  // block 1 of tile t-1, second part
             if constexpr (SG == 16) mask_block(s[0], vl_cur);                       // block 0 of tile t
-            if constexpr (SG >= 17 && SG <= 20) max_step(ic<SG - 17>{}, s[0], mxa);
-            if constexpr (SG == 21) max_halves(mxa);
-            if constexpr (SG == 23) update_block(ic<0>{}, mxa);
+            if constexpr (SG >= 17 && SG <= 20 && !NOMAX) max_step(ic<SG - 17>{}, s[0], mxa);
+            if constexpr (SG == 21 && !NOMAX) max_halves(mxa);
+            if constexpr (SG == 23 && !NOMAX) update_block(ic<0>{}, mxa);
             if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{});
             if constexpr (SG == 32) mask_block(s[1], vl_cur);                       // block 1 of tile t
-            if constexpr (SG >= 33 && SG <= 36) max_step(ic<SG - 33>{}, s[1], mxb);
-            if constexpr (SG == 37) max_halves(mxb);
-            if constexpr (SG == 39) update_block(ic<1>{}, mxb);
+            if constexpr (SG >= 33 && SG <= 36 && !NOMAX) max_step(ic<SG - 33>{}, s[1], mxb);
+            if constexpr (SG == 37 && !NOMAX) max_halves(mxb);
+            if constexpr (SG == 39 && !NOMAX) update_block(ic<1>{}, mxb);
             if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{});
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -362,12 +370,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // tiles 0 .. T4-1 (padding tiles are fully masked), one more tile's worth of slots for the pipelines in flight, then the
     // last three PV elements of block 2
-    for (int tb = 0;; tb += 4) {
-        tile(ic<0>{}, tb);
-        if (tb >= T4) break;
-        tile(ic<1>{}, tb + 1);
-        tile(ic<2>{}, tb + 2);
-        tile(ic<3>{}, tb + 3);
+    // Fixed reference point (as in attn64.hip): |s_ij| <= |q_i| max_j |k_j| =: M_i over ALL keys of the head, a fortiori over the
+    // gathered ones; if 2 M c <= 64 for every query of the wave, p = exp2((s - M) c) stays inside the normal range and the
+    // maxima / update / rescale work (48 of ~400 issues per tile) is not needed.  Per wave; changes nothing but rounding.
+    bool nomax = false;
+    if (p.kmax) {
+        const float km = p.kmax[bh];
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            float a = qss[qb], c2 = qss[qb];
+            lane_swap32(a, c2);
+            qss[qb] = __builtin_sqrtf(a + c2) * km;
+            ok = ok && (2.0f * qss[qb] * SCALE_LOG2E <= 64.0f);
+        }
+        nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        if (nomax) {
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) m[qb] = qss[qb], nmsc[qb] = -qss[qb] * SCALE_LOG2E, mlag[qb] = INFINITY;
+        }
+    }
+    if (nomax) {
+        for (int tb = 0;; tb += 4) {
+            tile(ic<0>{}, ic<1>{}, tb);
+            if (tb >= T4) break;
+            tile(ic<1>{}, ic<1>{}, tb + 1);
+            tile(ic<2>{}, ic<1>{}, tb + 2);
+            tile(ic<3>{}, ic<1>{}, tb + 3);
+        }
+    } else {
+        for (int tb = 0;; tb += 4) {
+            tile(ic<0>{}, ic<0>{}, tb);
+            if (tb >= T4) break;
+            tile(ic<1>{}, ic<0>{}, tb + 1);
+            tile(ic<2>{}, ic<0>{}, tb + 2);
+            tile(ic<3>{}, ic<0>{}, tb + 3);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfw[1]), "+v"(vfw[2]), "+v"(vfw[3]));
     mfma_pv<2, 1>(vfw[1], pw[2][1]);
@@ -498,5 +536,7 @@ extern "C" int chipmunk_attn96_prof_read(unsigned long long *out) {
 // gathered attention over the work plan built by launch_attn (attn.hip); inplace = 1 for the accumulate forms
 int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream) {
     CM_CHECK(p.plan && p.tickets && p.ws, "csp96: work plan missing");
-    return inplace ? launch96<true>(p, grid, stream) : launch96<false>(p, grid, stream);
+    AttnParams pp = p;
+    pp.kmax = chipmunk_knorm_max(p.k, p.ks, p.B, p.H, p.Nk, stream);
+    return inplace ? launch96<true>(pp, grid, stream) : launch96<false>(pp, grid, stream);
 }

@@ -40,3 +40,5 @@ int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
 // attn96.hip: gathered attention, two waves x 96 rows per 192-row group, two workgroups per CU (plan as for csp64)
 int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
+// attn64.hip: max_j |k_j| per (batch, head) into library scratch (nullptr if switched off / unavailable); see AttnParams::kmax
+const float *chipmunk_knorm_max(const uint16_t *k, const int64_t ks[3], int B, int H, int Nk, hipStream_t stream);
