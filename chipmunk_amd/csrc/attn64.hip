@@ -42,7 +42,7 @@ constexpr float MAX_LAG = 4.0f;
 #define A64_EB 20  // go one per gap into the next PV phase
 #endif
 #ifndef A64_EA
-#define A64_EA 40
+#define A64_EA 35   // (20 / 35 / 9: with the fixed reference point the first gaps of the PV phase carry no maxima and take nine steps)
 #endif
 #ifndef A64_VSPREAD   // V^T fragment reads: 0 = one per gap in phase A gaps 0..15, 1 = every other gap 0..30
 #define A64_VSPREAD 0
