@@ -245,3 +245,43 @@ def test_dense64_fixed_reference_point_and_its_fallback(dev, forced, scale, expe
     torch.testing.assert_close(l2.cpu(), l_ref, rtol=1e-3, atol=0)
     if expect == "running":
         assert torch.equal(o, o2) and torch.equal(l, l2), "inputs too large for the bound: both runs take the running-maximum loop"
+
+
+def test_long_launch_kernels_are_hipgraph_capturable(dev):
+    """the one-wave-per-SIMD kernels with their pre-pass (memset + K row-norm kernel, work plan) captured into a graph and
+    replayed on new data: nothing allocates or synchronises once the per-stream scratch has its size"""
+    import math
+    from chipmunk_amd import _native
+    from helpers import random_index_sets
+    H, n, count = 2, 1536, 512
+    G = math.ceil(n / 192)
+    q, k, v = [randn_bf16(1, H, n, 128, seed=s).to(dev) for s in (31, 32, 33)]
+    inds, counts = [t.to(dev) for t in random_index_sets(1, H, G, n, count, n, seed=7)]
+    opts = ("attn_dense64", "attn_colsum64", "attn_csp96")
+    for o in opts:
+        _native.set_option(o, 1)
+    try:
+        def step():
+            od, l = torch.ops.chipmunk.dense_attn(q, k, v)
+            o2, cs, l2 = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)
+            os_ = torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts)
+            return od, l, cs, os_
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                       # scratch of the capture stream reaches its size
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            captured = step()
+        q.copy_(randn_bf16(1, H, n, 128, seed=41).to(dev))   # new data, same buffers
+        k.copy_(randn_bf16(1, H, n, 128, seed=42).to(dev))
+        g.replay()
+        torch.cuda.synchronize()
+        eager = step()
+        torch.cuda.synchronize()
+        for a, b in zip(eager, captured):
+            assert torch.equal(a, b)
+    finally:
+        for o in opts:
+            _native.set_option(o, 0)
