@@ -969,6 +969,12 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     if (use_dense64(B, H, Nq, Nk)) {
         CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
                  "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
+        // one pass (attn64.hip MODE 3: the column sums ride the dense kernel's softmax pipeline) when the partial-sum scratch
+        // is available; option attn_fused_colsum = 2 keeps the two passes
+        if (chipmunk_get_option("attn_fused_colsum") != 2) {
+            if (float *part = (float *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(B, H, Nq, Nk)))
+                return chipmunk_dense64_colsum_launch(p, part, st);
+        }
         rc = chipmunk_dense64_launch(q, k, v, o, l, p.qs, p.ks, p.vs, p.os, B, H, Nq, Nk, st);
     } else {
         rc = launch_attn<false, false, true>(p, st);

@@ -92,6 +92,30 @@ __device__ __forceinline__ void lds_k(uint32_t addr) {
     constexpr int ka = 192 + (KB * 8 + KS) * 4;
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(ka), "i"(ka + 3), "i"(SLOT * TB + KB * 8192) : "memory");
 }
+// ---- cross-lane reduce-scatter steps of the fused column sums (MODE 3).  Two registers a, b hold values of two different
+// keys, one per lane (= query); after the step `a` holds, in the lanes whose bit B is 0, key a summed over the lane pair
+// (lane, partner) and, in the lanes whose bit B is 1, key b likewise: half the registers per step, no selects.
+//   bit 4: v_permlane16_swap (odd rows of a <-> even rows of b), then one add        (inputs written >= 2 instructions ago)
+//   bit 3: two bank-masked DPP adds, partner = row_mirror (15 - i: the bits below are flipped too, which the later steps
+//          sum over anyway);   bit 2: the same with row_half_mirror (7 - i), banks 0 / 2 keep a, banks 1 / 3 keep b
+//   bits 1, 0: inside a quad there is no lane mask: two selects and one DPP add (quad_perm)
+__device__ __forceinline__ void cs_pair16(float &a, float &b) {
+    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+}
+__device__ __forceinline__ void cs_pair8(float &a, const float &b) {
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(a) : "v"(b));
+}
+__device__ __forceinline__ void cs_pair4(float &a, const float &b) {
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(a) : "v"(b));
+}
+template <int CTRL>
+__device__ __forceinline__ float cs_pair_quad(float a, float b, bool hi) {
+    const float keep = hi ? b : a, give = hi ? a : b;
+    return keep + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), CTRL, 0xf, 0xf, true));
+}
 // Largest row norm of K per (batch, head): one 16-lane group per row (a lane squares its 8 elements, DPP row sum), maximum
 // over the block, one atomicMax on the float's bits (non-negative floats order like unsigned integers; the buffer is
 // zeroed by a memset node before every launch).  730 MB of K at HunyuanVideo size: ~0.2 ms beside a 130 ms launch.
@@ -132,7 +156,8 @@ __global__ __launch_bounds__(256) void knorm_max_kernel(const uint16_t *k, const
 //   and merged by the last arriver).
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn64_kernel(const AttnParams p) {
-    constexpr bool GATHER = MODE != 0, INPLACE = MODE == 2;
+    constexpr bool GATHER = MODE == 1 || MODE == 2, INPLACE = MODE == 2;
+    constexpr bool CSUM = MODE == 3;   // dense + the column sums of dense_colsum_attn in the same pass (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,6 +348,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float mlag[2] = {-INFINITY, -INFINITY};   // m + the lag (in raw score units): the per-tile check is one compare per query block
     float lacc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float alpha[2] = {1.f, 1.f};
+    // CSUM: w = exp2(m c) p_i (the summand exp2(s c + log2 p_i) = P_ij w_i), lpq = log2 p_i, the reduction's last nodes,
+    // this lane's byte offset inside a tile's 64 partial sums and the wave's row of the partial-sum buffer
+    float wq[2] = {0.f, 0.f}, lpq[2] = {-1.0e30f, -1.0e30f}, c4[2] = {0.f, 0.f}, c5 = 0.f;
+    uint32_t csoff = 0;
+    __amdgpu_buffer_rsrc_t prsrc = krsrc;
+    if constexpr (CSUM) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qrow = row0 + qb * 32 + l31;
+            const float pl = qrow < p.Nq ? p.p_in[(int64_t)bh * p.Nq + qrow] : 0.f;
+            lpq[qb] = pl > 0.f ? __builtin_amdgcn_logf(pl) : -1.0e30f;   // (rows past Nq and p <= 0 contribute exp2(-huge) = 0)
+        }
+        // the lane that ends up with key row (kb, u, rr, hf) of the tile: kb = bit 0, u = bit 1, rr = bits 4 3 2 (lsb first)
+        const int rr = ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2);
+        csoff = 4u * (uint32_t)(32 * (lane & 1) + (rr & 3) + 8 * (2 * ((lane >> 1) & 1) + (rr >> 2)) + 4 * hf);
+        prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 4) + (g * 4 + w)) * p.Nk);
+    }
     // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
 #pragma unroll
     for (int e = 0; e < 64; ++e) px[e] = e < 20 ? 0.f : -INFINITY;
@@ -372,6 +414,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1] = pack_bf16x2(px[I], px[I + 1]);
                 pin(pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1]);
             });
+            if constexpr (CSUM) {
+                // column sums, in place in px once E / L / C are done with an element (three steps behind E): the weighted sum
+                // over the two query blocks lands in the qb = 1 element of each key, then the reduce-scatter over the 32 lanes
+                // of a half (a step per level), the four slab nodes (px[8], px[24], px[40], px[56]) -> c4 -> c5
+                static_for<ecum(K - 3), ecum(K - 2)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr (((I >> 3) & 1) == 0) px[I] *= wq[0];
+                    else px[I] = __builtin_fmaf(px[I], wq[1], px[I - 8]);
+                    pin(px[I]);
+                });
+                static_for<ecum(K - 4), ecum(K - 3)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr ((I & 9) == 9) { cs_pair16(px[I - 1], px[I]); pin(px[I - 1]); }
+                });
+                static_for<ecum(K - 5), ecum(K - 4)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr ((I & 11) == 11) cs_pair8(px[I - 3], px[I - 1]);
+                });
+                static_for<ecum(K - 6), ecum(K - 5)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr ((I & 15) == 15) cs_pair4(px[I - 7], px[I - 3]);
+                });
+                static_for<ecum(K - 7), ecum(K - 6)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr ((I & 31) == 31) { c4[I >> 5] = cs_pair_quad<0x4E>(px[I - 23], px[I - 7], (lane & 2) != 0); pin(c4[I >> 5]); }
+                });
+                static_for<ecum(K - 8), ecum(K - 7)>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr (I == 63) { c5 = cs_pair_quad<0xB1>(c4[0], c4[1], (lane & 1) != 0); pin(c5); }
+                });
+            }
         }
     };
 
@@ -439,7 +512,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
-            if constexpr (G < 12) finish_step(ic<52 + G>{});
+            if constexpr (G < (CSUM ? 17 : 12)) finish_step(ic<52 + G>{});
+            if constexpr (CSUM && G == 17) {
+                // tile t-1's 64 column sums over this wave's 64 queries: one dword per lane into the wave's partial row (a ragged
+                // last tile stores only its own keys, a padding tile nothing)
+                const int tb1 = tile_base(t - 1), dd = (t - 1) * KT - tb1;
+                if (t > 0 && dd < KT) {
+                    if (dd <= 0 || (int)(csoff >> 2) >= dd)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c5), prsrc, csoff, (uint32_t)tb1 * 4u, 0);
+                }
+            }
             if constexpr (!(A64_ABL & 16) && !GATHER && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
                 constexpr int PC = (G - 16) >> 1;
                 if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
@@ -517,6 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     m[q2] = m_new;
                     nmsc[q2] = -m_new * SCALE_LOG2E;
                     mlag[q2] = m_new + LAG_RAW;
+                    if constexpr (CSUM) wq[q2] = fminf(__builtin_amdgcn_exp2f(m_new * SCALE_LOG2E + lpq[q2]), 1.0e37f);
                 }
             }
         }
@@ -559,7 +642,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
             if (nomax) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) m[qb] = qss[qb], nmsc[qb] = -qss[qb] * SCALE_LOG2E, mlag[qb] = INFINITY;
+                for (int qb = 0; qb < 2; ++qb) {
+                    m[qb] = qss[qb], nmsc[qb] = -qss[qb] * SCALE_LOG2E, mlag[qb] = INFINITY;
+                    if constexpr (CSUM) wq[qb] = fminf(__builtin_amdgcn_exp2f(qss[qb] * SCALE_LOG2E + lpq[qb]), 1.0e37f);
+                }
             }
         }
     }
@@ -891,12 +977,62 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
     return launch64<0>(p, (int64_t)B * H * p.G, stream);
 }
 
+// ---- dense_colsum_attn in one pass (MODE 3).  cs[bh][g][j] = sum over the group's rows i of exp2(s_ij c + log2 p_i) =
+// sum_i P_ij w_i with the P the softmax pipeline has in registers anyway and w_i = exp2(m_i c) p_i (m = the reference
+// point).  S^T puts the queries on the lanes, so the sum over a wave's 64 queries is a 5-level reduce-scatter over the 32
+// lanes of a half (cs_pair*: 64 + 63 VALU operations per 64-key tile beside ~2 500 cycles of MFMA) instead of the second
+// pass's 96 MFMAs and 192 exponentials per 192 rows; every wave stores its 64 sums per tile into its own fp32 row and
+// cs_combine_kernel adds the three rows of a group (fixed order: the result does not depend on scheduling).
+namespace {
+__global__ __launch_bounds__(256) void cs_combine_kernel(const float *part, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
+    const int g = blockIdx.y, bh = blockIdx.z;
+    const float *src = part + ((int64_t)bh * NRB + 3 * g) * Nk;
+    uint16_t *dst = cs + ((int64_t)bh * G + g) * cs_stride;
+    const int nrows = min(3, min(NRB - 3 * g, (Nq - 3 * g * 64 + 63) / 64));
+    if (((Nk | cs_stride) & 3) == 0) {
+        const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (j >= Nk) return;
+        f32x4 acc = *(const f32x4 *)(src + j);
+        for (int r = 1; r < nrows; ++r) {
+            const f32x4 x = *(const f32x4 *)(src + (int64_t)r * Nk + j);
+            acc[0] += x[0], acc[1] += x[1], acc[2] += x[2], acc[3] += x[3];
+        }
+        *(u32x2 *)(dst + j) = (u32x2){pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+    } else {
+        for (int e = 0; e < 4; ++e) {
+            const int j = (blockIdx.x * 256 + threadIdx.x) * 4 + e;
+            if (j >= Nk) return;
+            float acc = src[j];
+            for (int r = 1; r < nrows; ++r) acc += src[(int64_t)r * Nk + j];
+            dst[j] = f32_to_bf16_bits(acc);
+        }
+    }
+}
+}  // namespace
+
 // column-sum pass of dense_colsum_attn, one wave per 192-row group (p.p_in, p.cs, p.cs_stride, p.G = groups of 192)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
     static uint64_t lds_set = 0;
     ensure_dynamic_lds((const void *)colsum64_kernel, NSL * TB, lds_set);
     const int64_t grid = (int64_t)p.B * p.H * ((p.G + 3) / 4);
     hipLaunchKernelGGL(colsum64_kernel, dim3((unsigned)grid), dim3(256), NSL * TB, stream, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk) {
+    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)Nk * sizeof(float);
+}
+
+int chipmunk_dense64_colsum_launch(const AttnParams &p0, float *part, hipStream_t stream) {
+    AttnParams p = p0;
+    const int G192 = p.G;
+    p.G = (p.Nq + WGROWS - 1) / WGROWS;
+    p.cs_part = part;
+    p.kmax = chipmunk_knorm_max(p.k, p.ks, p.B, p.H, p.Nk, stream);
+    if (int rc = launch64<3>(p, (int64_t)p.B * p.H * p.G, stream)) return rc;
+    hipLaunchKernelGGL(cs_combine_kernel, dim3((unsigned)((p.Nk + 1023) / 1024), (unsigned)G192, (unsigned)(p.B * p.H)), dim3(256), 0, stream,
+                       part, p.cs, p.G * 4, G192, p.Nq, p.Nk, p.cs_stride);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

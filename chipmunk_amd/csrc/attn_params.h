@@ -29,6 +29,8 @@ struct AttnParams {
     // a wave can prove |s_ij| <= |q_i| * kmax for all its queries; if that bound is small enough for the exponent range, the
     // exponentials are taken against the FIXED reference point |q_i| * kmax and the running-maximum work disappears.
     const float *kmax;
+    // attn64.hip MODE 3 (dense + fused column sums): fp32 partial column sums, one row of Nk per (batch*head, 64-row wave block)
+    float *cs_part;
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 
@@ -36,6 +38,10 @@ struct AttnParams {
 // attn64.hip: gathered attention over a work plan (p.plan, p.tickets, p.ws set by launch_attn); inplace = 1 for the
 // accumulate forms (o_out = o_in + o_scale * result); `grid` = plan entries
 int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
+// attn64.hip: dense attention with the column sums of dense_colsum_attn folded into the same pass (p.p_in, p.cs, p.cs_stride
+// set; `part` = scratch of chipmunk_colsum_part_bytes(...) bytes), followed by the combine of the per-wave partial sums
+int chipmunk_dense64_colsum_launch(const AttnParams &p, float *part, hipStream_t stream);
+size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk);
 // attn64.hip: the column-sum pass of dense_colsum_attn for long launches (one wave per 192-row group)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
 // attn96.hip: gathered attention, two waves x 96 rows per 192-row group, two workgroups per CU (plan as for csp64)

@@ -17,7 +17,7 @@ extern "C" int chipmunk_abi_version(void) { return 1; }
 #include <string.h>
 namespace {
 struct Option { const char *name; int value; };
-Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}};
+Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}, {"attn_fused_colsum", 0}};
 }
 int chipmunk_get_option(const char *name) {
     for (auto &o : g_options) if (strcmp(o.name, name) == 0) return o.value;
@@ -83,6 +83,30 @@ void *chipmunk_scratch(hipStream_t stream, size_t bytes) {
     if (hipMalloc(&ptr, want) != hipSuccess) return nullptr;
     if (hipMemsetAsync(ptr, 0, want, stream) != hipSuccess) {
         (void)hipFree(ptr);
+        return nullptr;
+    }
+    s.ptr = ptr, s.bytes = want;
+    return ptr;
+}
+// A second, separately grown buffer for the one multi-GB user (the per-wave partial column sums of the fused
+// dense_colsum_attn pass: 21 GB at HunyuanVideo size).  Not zeroed; nullptr if the device cannot spare it (the caller then
+// takes the two-pass route).
+void *chipmunk_big_scratch(hipStream_t stream, size_t bytes) {
+    static std::map<std::pair<int, hipStream_t>, Scratch> big;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    Scratch &s = big[{dev, stream}];
+    if (s.bytes >= bytes) return s.ptr;
+    if (s.ptr) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr, s.bytes = 0;
+    }
+    const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    void *ptr = nullptr;
+    if (hipMalloc(&ptr, want) != hipSuccess) {
+        (void)hipGetLastError();
         return nullptr;
     }
     s.ptr = ptr, s.bytes = want;

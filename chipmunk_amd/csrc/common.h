@@ -156,6 +156,7 @@ int chipmunk_get_option(const char *name);
 uint32_t chipmunk_next_random_salt();  // per-launch salt of the random-key hash (capi.hip)
 // zero-initialised, grow-only device scratch owned by the library, one per (device, stream); nullptr on failure
 void *chipmunk_scratch(hipStream_t stream, size_t bytes);
+void *chipmunk_big_scratch(hipStream_t stream, size_t bytes);   // separate multi-GB buffer, not zeroed; nullptr if unavailable
 // attn64.hip: dense attention, one wave per SIMD (see there); strides in elements, [batch, head, row]
 int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o, float *l, const int64_t qs[3],
                             const int64_t ks[3], const int64_t vs[3], const int64_t os[3], int B, int H, int Nq, int Nk,

@@ -161,10 +161,13 @@ def test_csp64_sliced_heavy_items_merge(dev, forced_csp):
 
 # ---- the one-wave-per-group column-sum pass (option attn_colsum64 = 1 forces it at test sizes) ----
 
-@pytest.mark.parametrize("n,nk", [(384, 384), (1000, 1000), (1984, 1984), (777, 200), (960, 64), (4160, 768)])
-def test_colsum64_vs_oracle(dev, n, nk):
+# route: "two_pass" = dense kernel + colsum64_kernel; "fused" = the column sums inside the dense kernel (attn64 MODE 3, the
+# default where the dense kernel runs), with the fixed reference point and ("fused_runmax") with the running maximum
+@pytest.mark.parametrize("route", ["two_pass", "fused", "fused_runmax"])
+@pytest.mark.parametrize("n,nk", [(384, 384), (1000, 1000), (1984, 1984), (777, 200), (960, 64), (4160, 768), (200, 192)])
+def test_colsum64_vs_oracle(dev, n, nk, route):
     """group counts that are not multiples of four (idle waves), ragged last groups, ragged / padding key tiles (stored
-    twice with the same values), fewer rows than one group"""
+    twice with the same values / only their own keys), fewer rows than one group, row blocks past the last row"""
     import math
     from chipmunk_amd import _native
     H = 2
@@ -176,18 +179,62 @@ def test_colsum64_vs_oracle(dev, n, nk):
     o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(q2, k, v, l0)
     _native.set_option("attn_colsum64", 1)
     _native.set_option("attn_dense64", 1)
+    _native.set_option("attn_fused_colsum", 2 if route == "two_pass" else 0)
+    _native.set_option("attn_nomax", 2 if route == "fused_runmax" else 0)
     try:
         o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))
         again = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))[1]
     finally:
-        _native.set_option("attn_colsum64", 0)
-        _native.set_option("attn_dense64", 0)
+        for opt in ("attn_colsum64", "attn_dense64", "attn_fused_colsum", "attn_nomax"):
+            _native.set_option(opt, 0)
     G = math.ceil(n / 192)
     assert cs.shape == (1, H, G, n) and cs.dtype == torch.bfloat16   # Nq columns, the first Nk meaningful (dense_colsum_attn.cu:580-583)
     assert_close_bf16(o, o_ref, what="colsum64 o")
     torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
     assert_close_bf16(cs[..., :nk], cs_ref[..., :nk], atol=2e-3, rtol=3e-2, what="colsum64 cs vs oracle")
     assert torch.equal(cs[..., :nk], again[..., :nk]), "no order-dependent reduction: run-to-run identical"
+
+
+@pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
+def test_fused_colsum_running_max_update_paths(dev, pattern):
+    """the fused column sums while the reference point of the exponentials moves (the weights exp2(m c) p_i change with
+    it, per query block, between two tiles): o, l and cs against the oracle; cs also against the two-pass route"""
+    from chipmunk_amd import _native
+    n, H = 1152, 2
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, H, n, 128, generator=g)
+    k = torch.randn(1, H, n, 128, generator=g)
+    v = torch.randn(1, H, n, 128, generator=g)
+    u = torch.randn(128, generator=g)
+    u = u / u.norm()
+    q = 0.3 * q + 3.0 * u
+    if pattern == "ramp":
+        k = 0.3 * k + (torch.arange(n).float() / n * 30.0)[None, None, :, None] * u
+    elif pattern == "descending":
+        k = 0.3 * k + ((n - torch.arange(n)).float() / n * 30.0)[None, None, :, None] * u
+    else:
+        k = 0.3 * k
+        j = 5 if pattern == "spike_first" else 1000
+        k[0, :, j] += 40.0 * u
+        q[0, :, ::3] *= 0.05
+    q, k, v = [t.to(torch.bfloat16) for t in (q, k, v)]
+    _, l0 = oracle.dense_attn(q, k, v)
+    o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(q, k, v, l0)
+    args = [t.to(dev) for t in (q, k, v, l0)]
+    _native.set_option("attn_dense64", 1)
+    _native.set_option("attn_colsum64", 1)
+    try:
+        o, cs, l = torch.ops.chipmunk.dense_colsum_attn(*args)
+        _native.set_option("attn_fused_colsum", 2)
+        o2, cs2, l2 = torch.ops.chipmunk.dense_colsum_attn(*args)
+    finally:
+        for opt in ("attn_colsum64", "attn_dense64", "attn_fused_colsum"):
+            _native.set_option(opt, 0)
+    assert_close_bf16(o, o_ref, what=f"fused colsum o, {pattern}")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=2e-3, atol=0)
+    assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what=f"fused cs vs oracle, {pattern}")
+    assert_close_bf16(cs, cs2.float().cpu(), atol=2e-3, rtol=3e-2, what=f"fused cs vs two-pass, {pattern}")
+    assert torch.equal(o, o2) and torch.equal(l, l2), "the column sums do not touch the attention result"
 
 
 @pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
