@@ -241,7 +241,7 @@ def pmc_traffic(op_name):
              "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
              "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"]}
     keys = parts.get(op_name, [])
-    for fname in ("r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
             continue
@@ -275,8 +275,8 @@ def _dense_work(q, k, v, *a):
 def _colsum_work(q, k, v, p):
     B, H, Nq, D = q.shape
     Nk = k.shape[2]
-    def work():  # dense pass + the K-only score pass
-        return 6.0 * B * H * Nq * Nk * D, 3 * B * H * Nq * D * 2 + 3 * B * H * Nk * D * 2 + B * H * ((Nq + 191) // 192) * Nk * 2
+    def work():  # one QK^T + PV pass (the column sums are reductions of the same probabilities): Q, O, K, V once + cs written
+        return 4.0 * B * H * Nq * Nk * D, 2 * B * H * Nq * D * 2 + 2 * B * H * Nk * D * 2 + B * H * ((Nq + 191) // 192) * Nk * 2
     return work
 
 

@@ -99,9 +99,10 @@ __device__ __forceinline__ void lds_k(uint32_t addr) {
 //   bit 3: two bank-masked DPP adds, partner = row_mirror (15 - i: the bits below are flipped too, which the later steps
 //          sum over anyway);   bit 2: the same with row_half_mirror (7 - i), banks 0 / 2 keep a, banks 1 / 3 keep b
 //   bits 1, 0: inside a quad there is no lane mask: two selects and one DPP add (quad_perm)
-__device__ __forceinline__ void cs_pair16(float &a, float &b) {
-    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    a += b;
+// (two pairs per statement: each add sits one instruction behind its swap, which is the wait state the swap's result needs)
+__device__ __forceinline__ void cs_pair16x2(float &a, float &b, float &c, float &d) {
+    asm volatile("v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %2, %2, %3"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 __device__ __forceinline__ void cs_pair8(float &a, const float &b) {
     asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 });
                 static_for<ecum(K - 4), ecum(K - 3)>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
-                    if constexpr ((I & 9) == 9) { cs_pair16(px[I - 1], px[I]); pin(px[I - 1]); }
+                    if constexpr ((I & 11) == 11) cs_pair16x2(px[I - 3], px[I - 2], px[I - 1], px[I]);
                 });
                 static_for<ecum(K - 5), ecum(K - 4)>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;

@@ -195,6 +195,28 @@ def test_colsum64_vs_oracle(dev, n, nk, route):
     assert torch.equal(cs[..., :nk], again[..., :nk]), "no order-dependent reduction: run-to-run identical"
 
 
+def test_fused_colsum_strided_batched_and_degenerate_p(dev):
+    """[B, N, H, D] storage viewed as [B, H, N, D], two batches; rows whose p is 0 (they must add nothing to the column
+    sums, as in the two-pass kernels) and rows whose p is large"""
+    from chipmunk_amd import _native
+    B, H, N = 2, 3, 640
+    base = [randn_bf16(B, N, H, 128, seed=s).to(dev) for s in (51, 52, 53)]
+    q, k, v = [t.permute(0, 2, 1, 3) for t in base]
+    qc, kc, vc = [t.cpu().contiguous() for t in (q, k, v)]
+    _, l0 = oracle.dense_attn(qc, kc, vc)
+    l0[:, :, 5::7] = 0.0
+    l0[:, :, 3::11] *= 1.0e6
+    o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(qc, kc, vc, l0)
+    _native.set_option("attn_dense64", 1)
+    try:
+        o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l0.to(dev))
+    finally:
+        _native.set_option("attn_dense64", 0)
+    assert_close_bf16(o, o_ref, what="fused colsum, strided o")
+    torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
+    assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what="fused colsum, strided cs")
+
+
 @pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
 def test_fused_colsum_running_max_update_paths(dev, pattern):
     """the fused column sums while the reference point of the exponentials moves (the weights exp2(m c) p_i change with

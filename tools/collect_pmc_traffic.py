@@ -37,7 +37,7 @@ def one_pass(counter, what, extra_env=None):
 
 C3_KERNELS = {  # HunyuanVideo shapes (bench.py workload hunyuan_c3): kbench cases with all 24 heads
     "csp_128_attn_c3": "csp96_kernel<true>", "dense_attn_c3": "attn64_kernel<0>",   # long launches: attn96.hip / attn64.hip
-    "colsum_pass_c3": "colsum64_kernel",
+    "dense_colsum_kernel_c3": "attn64_kernel<3>", "colsum_combine_c3": "cs_combine_kernel",   # dense_colsum_attn: fused pass + combine
 }
 
 
@@ -52,9 +52,9 @@ def main(tag):
             res[key] = {"FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB_raw": w[0], "hbm_bytes_per_launch": (2.0 * f[0] + w[0]) * 1024.0,
                         "note": "24 heads x 119 056 tokens; sparse: 9 088 sorted random keys per 192-query group (the bench's mean "
                                 "count), in-place accumulate form; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE uncorrected"}
-    if "dense_attn_c3" in res and "colsum_pass_c3" in res:
-        res["dense_colsum_attn_c3"] = {"hbm_bytes_per_launch": res["dense_attn_c3"]["hbm_bytes_per_launch"] + res["colsum_pass_c3"]["hbm_bytes_per_launch"],
-                                       "note": "dense pass + K-only column-sum pass"}
+    if "dense_colsum_kernel_c3" in res and "colsum_combine_c3" in res:
+        res["dense_colsum_attn_c3"] = {"hbm_bytes_per_launch": res["dense_colsum_kernel_c3"]["hbm_bytes_per_launch"] + res["colsum_combine_c3"]["hbm_bytes_per_launch"],
+                                       "note": "dense pass with the column sums folded in (fp32 partial sums per 64-row wave block) + the combine of the partials"}
     for what, keys, fused in ((["mm1", "mm2", "scatter", "csp_flux", "dense_flux"], list(KERNELS), False),
                               (["mm1s"], ["mm1"], True)):
         fetch, write = one_pass("FETCH_SIZE", what), one_pass("WRITE_SIZE", what)
