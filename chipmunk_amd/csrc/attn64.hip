@@ -396,8 +396,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return k <= 0 ? 0 : k <= 20 ? (k * A64_EB) / 20 : k <= 52 ? A64_EB + ((k - 20) * A64_EA) / 32
                                                                   : (A64_EB + A64_EA + (k - 52) < 64 ? A64_EB + A64_EA + (k - 52) : 64);
     };
-    auto finish_step = [&](auto kk) __attribute__((always_inline)) {
+    auto finish_step = [&](auto kk, auto uwc) __attribute__((always_inline)) {
         constexpr int K = decltype(kk)::value;
+        constexpr bool UW = decltype(uwc)::value != 0;   // CSUM with unit weights (reference point = the previous step's normaliser)
         if constexpr (!(A64_ABL & 1)) {
             static_for<ecum(K), ecum(K + 1)>([&](auto ii) {           // E
                 constexpr int I = decltype(ii)::value;
@@ -421,9 +422,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // of a half (a step per level), the four slab nodes (px[8], px[24], px[40], px[56]) -> c4 -> c5
                 static_for<ecum(K - 3), ecum(K - 2)>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
-                    if constexpr (((I >> 3) & 1) == 0) px[I] *= wq[0];
-                    else px[I] = __builtin_fmaf(px[I], wq[1], px[I - 8]);
-                    pin(px[I]);
+                    if constexpr (UW) {
+                        if constexpr (((I >> 3) & 1) == 1) { px[I] += px[I - 8]; pin(px[I]); }
+                    } else {
+                        if constexpr (((I >> 3) & 1) == 0) px[I] *= wq[0];
+                        else px[I] = __builtin_fmaf(px[I], wq[1], px[I - 8]);
+                        pin(px[I]);
+                    }
                 });
                 static_for<ecum(K - 4), ecum(K - 3)>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto tile = [&](auto slc, auto nmc, int t) __attribute__((always_inline)) {
         constexpr int SL = decltype(slc)::value;
         constexpr bool NOMAX = decltype(nmc)::value != 0;   // fixed reference point (see below): no maxima, no update, no rescale
+        constexpr auto uwc = ic<(CSUM && decltype(nmc)::value == 2) ? 1 : 0>{};
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago: the issues of the last two iterations may stay in flight
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (PC < 4) issue_k1(ksoff, ldsw, SL, PC);
                 else issue_v1(vsoff, ldsw, (SL + 2) & 3, PC - 4);
             }
-            finish_step(ic<20 + G>{});
+            finish_step(ic<20 + G>{}, uwc);
             if constexpr (A64_VSPREAD ? (G & 1) == 0 : G < 16) {   // all sixteen V^T fragments of tile t-1: the LDS pipe carries V in phase A and K
                 constexpr int f = A64_VSPREAD ? G >> 1 : G;        // in phase B (each wave reads both tiles whole: 2 x 64 KiB per CU and tile = 1024 LDS cycles)
                 if constexpr (A64_ABL & 4) vf[f] = (u32x4){(uint32_t)t, 1u, 2u, 3u};
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
-            if constexpr (G < (CSUM ? 17 : 12)) finish_step(ic<52 + G>{});
+            if constexpr (G < (CSUM ? 17 : 12)) finish_step(ic<52 + G>{}, uwc);
             if constexpr (CSUM && G == 17) {
                 // tile t-1's 64 column sums over this wave's 64 queries: one dword per lane into the wave's partial row (a ragged
                 // last tile stores only its own keys, a padding tile nothing)
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     pin(px[I]);
                 });
             }
-            if constexpr (G >= 12) finish_step(ic<G - 12>{});
+            if constexpr (G >= 12) finish_step(ic<G - 12>{}, uwc);
             __builtin_amdgcn_sched_barrier(0);
         };
         static_for<0, 12>(phase_b_gap);
@@ -650,7 +656,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
-    if (nomax) {
+    // CSUM: with the reference point of query i at -log2 p_i (the previous step's normaliser) the summand of the column sums
+    // IS the P of the softmax pipeline (w = 1: the weighting costs one add per key instead of a multiply and a
+    // multiply-add).  Taken when every query of the wave has a usable p and |s c| + |log2 p| stays far inside the exponent
+    // range; p.probe & 4 keeps the weighted form (A/B, tests).
+    bool unitw = false;
+    if constexpr (CSUM) {
+        if (nomax && !(p.probe & 4)) {
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) ok = ok && lpq[qb] > -1.0e29f && qss[qb] * SCALE_LOG2E + __builtin_fabsf(lpq[qb]) <= 80.0f;
+            unitw = __builtin_amdgcn_ballot_w64(!ok) == 0;
+            if (unitw) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) m[qb] = -lpq[qb] / SCALE_LOG2E, nmsc[qb] = lpq[qb];
+            }
+        }
+    }
+    if (CSUM && unitw) {
+        if constexpr (CSUM) {
+            for (int tb = 0;; tb += 4) {
+                tile(ic<0>{}, ic<2>{}, tb);
+                if (tb >= T4) break;
+                tile(ic<1>{}, ic<2>{}, tb + 1);
+                tile(ic<2>{}, ic<2>{}, tb + 2);
+                tile(ic<3>{}, ic<2>{}, tb + 3);
+            }
+        }
+    } else if (nomax) {
         for (int tb = 0;; tb += 4) {
             tile(ic<0>{}, ic<1>{}, tb);
             if (tb >= T4) break;
@@ -1030,6 +1063,7 @@ int chipmunk_dense64_colsum_launch(const AttnParams &p0, float *part, hipStream_
     const int G192 = p.G;
     p.G = (p.Nq + WGROWS - 1) / WGROWS;
     p.cs_part = part;
+    if (chipmunk_get_option("attn_fused_colsum") == 3) p.probe |= 4;   // weighted column sums even where unit weights would do
     p.kmax = chipmunk_knorm_max(p.k, p.ks, p.B, p.H, p.Nk, stream);
     if (int rc = launch64<3>(p, (int64_t)p.B * p.H * p.G, stream)) return rc;
     hipLaunchKernelGGL(cs_combine_kernel, dim3((unsigned)((p.Nk + 1023) / 1024), (unsigned)G192, (unsigned)(p.B * p.H)), dim3(256), 0, stream,
