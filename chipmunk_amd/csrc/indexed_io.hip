@@ -16,6 +16,18 @@ namespace {
 //   C. popcounts + a per-class scan over blocks + a scan over classes give every (class, block) cell its output offset;
 //   D. each lane walks the set bits of its cell and writes the column numbers;
 //   E. one lane appends the padding columns from the untransposed words.
+// inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast:15 and :31
+// across them) -- the __shfl_up form is six ds_bpermute round trips through the LDS crossbar, each with its index
+// arithmetic and select, and the sorted compaction below runs two such chains per 2 048 columns.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 struct M2IParams {
     const uint8_t *mask;  // bool bytes [rows, n]  (PACKED == false)  or packed bits [rows*n/8] (PACKED == true)
     int32_t *indices;
@@ -97,24 +109,17 @@ __global__ __launch_bounds__(256) void mask_to_indices_kernel(const M2IParams p)
         // per-thread-chunk form wrote 256 separate streams per row: 0.95 ms per C3 layer).
         uint32_t *blktot = (uint32_t *)T;   // [NB + 1] (the transpose matrix is not used by this variant)
         for (int blk = w; blk < NB; blk += 4) {
-            uint32_t c = __popc(bits[blk * 64 + lane]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-            if (lane == 0) blktot[blk] = c;
+            const uint32_t c = wave_incl_scan(__popc(bits[blk * 64 + lane]));
+            if (lane == 63) blktot[blk] = c;
         }
         __syncthreads();
         if (w == 0) {   // exclusive scan of the block totals, 64 blocks per step
             uint32_t run = 0;
             for (int b0 = 0; b0 < NB; b0 += 64) {
                 const uint32_t v = b0 + lane < NB ? blktot[b0 + lane] : 0u;
-                uint32_t incl = v;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
-                }
+                const uint32_t incl = wave_incl_scan(v);
                 if (b0 + lane < NB) blktot[b0 + lane] = run + incl - v;
-                run += __shfl(incl, 63);
+                run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
             if (lane == 0) blktot[NB] = run;
         }
@@ -123,12 +128,7 @@ __global__ __launch_bounds__(256) void mask_to_indices_kernel(const M2IParams p)
         for (int blk = w; blk < NB; blk += 4) {
             uint32_t v = bits[blk * 64 + lane];
             const uint32_t c = __popc(v);
-            uint32_t incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
+            const uint32_t incl = wave_incl_scan(c);
             int pos = (int)(blktot[blk] + incl - c);
             const int col0 = (blk * 64 + lane) * 32;
             while (v) {

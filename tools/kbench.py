@@ -233,6 +233,8 @@ def bench_io(which):
         ms = timeit(lambda: chipmunk_amd.ops.packed_mask_to_indices(packed, shp, 128, 192), reps=5)
         byts = H * G * N / 8 + 4 * 0.06 * H * G * N
         print(f"packed_mask_to_indices           : {ms*1e3:8.1f} us  {byts/ms/1e6:7.1f} GB/s algorithmic")
+        ms = timeit(lambda: chipmunk_amd.ops.mask_to_sorted_indices(packed, shp, 128, 192), reps=5)
+        print(f"packed mask -> sorted indices    : {ms*1e3:8.1f} us  {byts/ms/1e6:7.1f} GB/s algorithmic")
         ms = timeit(lambda: chipmunk_amd.ops.bitunpack(packed, shp), reps=5)
         print(f"bitunpack                        : {ms*1e3:8.1f} us  {(H*G*N*1.125)/ms/1e6:7.1f} GB/s")
         ms = timeit(lambda: chipmunk_amd.ops.bitpack(mask), reps=5)
