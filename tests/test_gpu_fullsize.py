@@ -39,6 +39,38 @@ def test_c3_sparse_attention_with_all_keys_equals_dense(dev):
     torch.testing.assert_close(l[:, :, rows], lref, rtol=2e-3, atol=0)
 
 
+def test_c3_fused_column_sums_are_a_partition_of_unity(dev):
+    """HunyuanVideo C3 sequence, 2 heads, the one-pass dense_colsum_attn (the route the bench takes).  With p = this very
+    call's own l, the summand exp(s_ij) p_i is the softmax probability: every query row contributes exactly 1 to the sum of
+    its group's column sums, so sum_j cs[g, j] = rows of group g (192; 16 in the last).  Size-independent, exercises all
+    1 861 key tiles x 1 861 wave rows x the combine; plus: same o / l as dense_attn, cs equal to the two-pass route, and
+    one group checked against an fp32 reference."""
+    from chipmunk_amd import _native
+    N, H = 119056, 2
+    g = torch.Generator(device=dev).manual_seed(7)
+    q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
+    G = math.ceil(N / 192)
+    o_d, l = torch.ops.chipmunk.dense_attn(q, k, v)
+    o, cs, l2 = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)
+    assert cs.shape == (1, H, G, N)
+    assert_close_bf16(o, o_d.float().cpu(), atol=4e-3, rtol=1e-2, what="C3 one-pass o vs dense_attn")
+    torch.testing.assert_close(l2, l, rtol=2e-3, atol=0)
+    tot = cs.float().sum(-1)
+    rows = torch.full((G,), 192.0, device=dev)
+    rows[-1] = N - 192 * (G - 1)
+    torch.testing.assert_close(tot, rows.expand(1, H, G), rtol=5e-3, atol=0)
+    _native.set_option("attn_fused_colsum", 2)
+    try:
+        cs_two = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)[1]
+    finally:
+        _native.set_option("attn_fused_colsum", 0)
+    assert_close_bf16(cs, cs_two.float().cpu(), atol=1e-5, rtol=2e-2, what="C3 column sums, one pass vs two")
+    gi = 300
+    qs = q[0, 1, gi * 192:(gi + 1) * 192].float()
+    p_ref = torch.exp(qs @ k[0, 1].float().T / math.sqrt(128)) * l[0, 1, gi * 192:(gi + 1) * 192]
+    assert_close_bf16(cs[0, 1, gi], p_ref.sum(0).cpu(), atol=1e-5, rtol=2e-2, what="C3 column sums of one group vs fp32")
+
+
 def test_c3_cache_plus_delta_identity(dev):
     """The identity the method rests on, at C3 size: o_cache = dense - sparse; o_cache + sparse == dense."""
     N, H, count = 119056, 1, 7296
