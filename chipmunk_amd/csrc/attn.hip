@@ -972,8 +972,31 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
         // one pass (attn64.hip MODE 3: the column sums ride the dense kernel's softmax pipeline) when the partial-sum scratch
         // is available; option attn_fused_colsum = 2 keeps the two passes
         if (chipmunk_get_option("attn_fused_colsum") != 2) {
-            if (float *part = (float *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(B, H, Nq, Nk)))
-                return chipmunk_dense64_colsum_launch(p, part, st);
+            // all (batch, head) pairs in one launch if the partial sums fit (21 GB at HunyuanVideo size), else in chunks of heads
+            // -- halved until the buffer can be had, down to one head (0.9 GB)
+            int hc = H;
+            float *part = nullptr;
+            const int hc_min = chipmunk_get_option("attn_fused_colsum") == 4 ? 1 : 0;   // 4: one head per launch (test of the chunked form)
+            if (hc_min) hc = 1;
+            for (; hc >= 1; hc /= 2) {
+                part = (float *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(hc == H ? B : 1, hc, Nq, Nk));
+                if (part) break;
+            }
+            if (part && hc == H) return chipmunk_dense64_colsum_launch(p, part, st);
+            if (part) {
+                for (int b = 0; b < B; ++b)
+                    for (int h0 = 0; h0 < H; h0 += hc) {
+                        AttnParams c = p;
+                        const int hn = H - h0 < hc ? H - h0 : hc;
+                        const int64_t bh0 = (int64_t)b * H + h0;
+                        c.q += b * p.qs[0] + h0 * p.qs[1], c.k += b * p.ks[0] + h0 * p.ks[1], c.v += b * p.vs[0] + h0 * p.vs[1];
+                        c.o += b * p.os[0] + h0 * p.os[1];
+                        c.l_out += bh0 * Nq, c.p_in += bh0 * Nq, c.cs += bh0 * p.G * (int64_t)cs_stride;
+                        c.B = 1, c.H = hn;
+                        if (int e = chipmunk_dense64_colsum_launch(c, part, st)) return e;
+                    }
+                return CHIPMUNK_OK;
+            }
         }
         rc = chipmunk_dense64_launch(q, k, v, o, l, p.qs, p.ks, p.vs, p.os, B, H, Nq, Nk, st);
     } else {

@@ -163,8 +163,9 @@ def test_csp64_sliced_heavy_items_merge(dev, forced_csp):
 
 # route: "two_pass" = dense kernel + colsum64_kernel; "fused" = the column sums inside the dense kernel (attn64 MODE 3, the
 # default where the dense kernel runs): reference point -log2 p_i and unit weights where every query of a wave allows it,
-# "fused_weighted" = fixed reference point |q_i| max|k| with weights, "fused_runmax" = running maximum with weights
-@pytest.mark.parametrize("route", ["two_pass", "fused", "fused_weighted", "fused_runmax"])
+# "fused_weighted" = fixed reference point |q_i| max|k| with weights, "fused_runmax" = running maximum with weights,
+# "fused_per_head" = the chunked form (one launch per head: what runs when the partial-sum buffer cannot be had whole)
+@pytest.mark.parametrize("route", ["two_pass", "fused", "fused_weighted", "fused_runmax", "fused_per_head"])
 @pytest.mark.parametrize("n,nk", [(384, 384), (1000, 1000), (1984, 1984), (777, 200), (960, 64), (4160, 768), (200, 192)])
 def test_colsum64_vs_oracle(dev, n, nk, route):
     """group counts that are not multiples of four (idle waves), ragged last groups, ragged / padding key tiles (stored
@@ -180,7 +181,7 @@ def test_colsum64_vs_oracle(dev, n, nk, route):
     o_ref, cs_ref, l_ref = oracle.dense_colsum_attn(q2, k, v, l0)
     _native.set_option("attn_colsum64", 1)
     _native.set_option("attn_dense64", 1)
-    _native.set_option("attn_fused_colsum", {"two_pass": 2, "fused_weighted": 3}.get(route, 0))
+    _native.set_option("attn_fused_colsum", {"two_pass": 2, "fused_weighted": 3, "fused_per_head": 4}.get(route, 0))
     _native.set_option("attn_nomax", 2 if route == "fused_runmax" else 0)
     try:
         o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q2.to(dev), k.to(dev), v.to(dev), l0.to(dev))
@@ -211,8 +212,12 @@ def test_fused_colsum_strided_batched_and_degenerate_p(dev):
     _native.set_option("attn_dense64", 1)
     try:
         o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l0.to(dev))
+        _native.set_option("attn_fused_colsum", 4)      # one (batch, head) per launch: same kernels, same numbers
+        o4, cs4, l4 = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l0.to(dev))
     finally:
         _native.set_option("attn_dense64", 0)
+        _native.set_option("attn_fused_colsum", 0)
+    assert torch.equal(o, o4) and torch.equal(cs, cs4) and torch.equal(l, l4), "chunked launches change nothing"
     assert_close_bf16(o, o_ref, what="fused colsum, strided o")
     torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-3, atol=0)
     assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what="fused colsum, strided cs")
