@@ -828,8 +828,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int l31 = lane & 31, hf = lane >> 5, l15 = lane & 15, lg = lane >> 4;
     const int G4 = (p.G + 3) / 4;
     const int wid = blockIdx.x;
-    const int bh = wid / G4, g = (wid - bh * G4) * 4 + w;   // this wave's 192-row group (>= p.G: nothing to store)
-    const int b = bh / p.H, h = bh - b * p.H;
+    // (readfirstlane: the quotient comes out of the VALU; left in a VGPR, everything derived from it -- the K buffer resource
+    // above all -- is "uniform but in vector registers", and every LDS-DMA then becomes a readfirstlane waterfall loop that
+    // narrows and restores EXEC in the middle of the MFMA stream)
+    const int bh = __builtin_amdgcn_readfirstlane(wid / G4), g = (wid - bh * G4) * 4 + w;   // this wave's 192-row group (>= p.G: nothing to store)
+    const int b = __builtin_amdgcn_readfirstlane(bh / p.H), h = bh - b * p.H;
     const int row0 = g * 192;
     const int ntiles = (p.Nk + KT - 1) / KT;
     const int T4 = (ntiles + 3) & ~3;
@@ -946,7 +949,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float tot = a + c;
                     cacc[TP ^ 1][0] = 0.f, cacc[TP ^ 1][1] = 0.f;
                     if (g < p.G && t > 0)
-                        p.cs[((int64_t)bh * p.G + g) * p.cs_stride + tile_base(t - 1) + lane] = f32_to_bf16_bits(tot);
+                    {
+                        // (branch-free rounding: a divergent NaN path would toggle EXEC here as well)
+                        const uint32_t u = __float_as_uint(tot);
+                        const uint32_t rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16, qn = (u >> 16) | 0x0040u;
+                        p.cs[((int64_t)bh * p.G + g) * p.cs_stride + tile_base(t - 1) + lane] = (uint16_t)((u & 0x7fffffffu) > 0x7f800000u ? qn : rne);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
