@@ -241,7 +241,7 @@ def pmc_traffic(op_name):
              "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
              "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"]}
     keys = parts.get(op_name, [])
-    for fname in ("r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
             continue
