@@ -966,6 +966,10 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     // 885 vs 480 us at FLUX size, 36.9 vs 23.5 ms for two HunyuanVideo heads; removed.)
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    if (chipmunk_get_option("attn_fused_colsum") == 5) {   // probe: the K-only pass alone (o and l are not written)
+        if (use_colsum64(B, H, Nq, Nk)) return chipmunk_colsum64_launch(p, st);
+        return launch_attn<false, false, false, true>(p, st);
+    }
     if (use_dense64(B, H, Nq, Nk)) {
         CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
                  "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
