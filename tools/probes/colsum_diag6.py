@@ -24,5 +24,10 @@ for name, extra in (("colsum64 alone", {}), ("general K-only pass alone", {"attn
         _native.set_option("attn_fused_colsum", 0)
         for o in extra:
             _native.set_option(o, 0)
-        res.append(nbad(cs.float()))
+        a = cs.float()
+        res.append(nbad(a))
+        bad = ((a - f).abs() > 1e-5 + 2e-2 * f.abs()).nonzero().tolist()
+        ev = sorted({(h, gi, j // 64, (j % 64) // 32) for _, h, gi, j in bad})
+        if ev:
+            print("    events (head, group, 64-key tile, half):", ev)
     print(f"{name:28s} elements off vs one-pass over 8 launches: {res}")
