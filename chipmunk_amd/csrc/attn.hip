@@ -304,7 +304,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         };
         int it = 0;
         for (int t = 0; t < ntiles; t += 2, ++it) {
-            wait_vmcnt<0>();
+            // vmcnt: the tiles' DMA; lgkmcnt: this wave's ds_write of its partial sums into cs_acc -- the raw s_barrier does not
+            // wait for LDS traffic, and without it wave 0's flush could read a wave's partial of FOUR TILES AGO (same
+            // cs_acc slot) for the tile the wave finished last: seen at HunyuanVideo size as ~1 event per 10^6 wave-tiles, 32
+            // adjacent sums of an odd tile ~6 % off, never the same place twice (found by the one-pass route's cross-check)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (t > 0) flush(t - 2, it - 1);
             if (t + 2 < ntiles) issue_data(t + 2);
