@@ -223,6 +223,29 @@ def test_fused_colsum_strided_batched_and_degenerate_p(dev):
     assert_close_bf16(cs, cs_ref, atol=2e-3, rtol=3e-2, what="fused colsum, strided cs")
 
 
+def test_k_only_passes_are_run_to_run_identical_at_scale(dev):
+    """24 heads x 16 384: ~4 million wave-tiles per launch.  Regression test for the general kernel's K-only pass, which
+    handed its per-wave partial sums to wave 0 across a barrier without waiting for its own LDS writes (about one stale
+    partial per million wave-tiles: a few events per launch at this size); colsum64_kernel and the one-pass route beside it."""
+    from chipmunk_amd import _native
+    H, n = 24, 16384
+    q, k, v = [randn_bf16(1, H, n, 128, seed=s).to(dev) for s in (61, 62, 63)]
+    _, l = torch.ops.chipmunk.dense_attn(q, k, v)
+    ref = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)[1]
+    assert torch.equal(ref, torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)[1])
+    for which in (2, 1):
+        _native.set_option("attn_fused_colsum", 2)
+        _native.set_option("attn_colsum64", which)
+        try:
+            outs = [torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)[1] for _ in range(4)]
+        finally:
+            _native.set_option("attn_fused_colsum", 0)
+            _native.set_option("attn_colsum64", 0)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), f"K-only kernel {which}: launches differ"
+        assert_close_bf16(outs[0], ref.float().cpu(), atol=1e-5, rtol=2e-2, what=f"K-only kernel {which} vs one pass")
+
+
 @pytest.mark.parametrize("pattern", ["ramp", "spike", "spike_first", "descending"])
 def test_fused_colsum_running_max_update_paths(dev, pattern):
     """the fused column sums while the reference point of the exponentials moves (the weights exp2(m c) p_i change with
