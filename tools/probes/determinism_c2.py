@@ -1,0 +1,63 @@
+"""run-to-run identity of the FLUX-size (C2) operators: sparse MLP GEMMs, scatter-add, top-k / mask -> indices, FLUX attention.
+Each op 12 times on the same inputs (in-place ops on fresh copies); any launch that differs from the first is reported."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import chipmunk_amd
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+M, K, F, keep = 4352, 3072, 12288, 4096
+a = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
+bias = (torch.randn(F, device=dev, generator=g) * 0.1).to(torch.bfloat16)
+w1 = (torch.randn(F, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+cache0 = torch.randn(F, M, device=dev, dtype=torch.bfloat16, generator=g)
+packed0 = torch.randn(M, F, device=dev, dtype=torch.bfloat16, generator=g) * 0.1
+w2t = (torch.randn(F, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+out0 = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
+G = M // 128
+inds = torch.stack([torch.randperm(F, device=dev, generator=g) for _ in range(G)]).to(torch.int32)
+counts = torch.full((G,), keep, dtype=torch.int32, device=dev)
+def rep(name, fn, n=12):
+    ref = fn()
+    diff = sum(0 if all(torch.equal(x, y) for x, y in zip(ref, fn())) else 1 for _ in range(n - 1))
+    print(f"{name:34s} launches that differ from the first: {diff} of {n - 1}")
+def mm1():
+    p, c = packed0.clone(), cache0.clone()
+    torch.ops.chipmunk.csp_mlp_mm1(a, w1, p, bias, c, inds, counts)
+    return p, c
+def mm1s():
+    p, c = packed0.clone(), cache0.clone()
+    torch.ops.chipmunk.csp_mlp_mm1_scatter(a, w1, p, bias, c, inds, counts)
+    return p, c
+def mm2():
+    o = out0.clone()
+    torch.ops.chipmunk.csp_mlp_mm2(packed0, w2t, inds, counts, o)
+    return (o,)
+def scat():
+    c = cache0.clone()
+    torch.ops.chipmunk.csp_scatter_add(packed0[None], c[None], inds[None], counts[None], 6)
+    return (c,)
+rep("csp_mlp_mm1", mm1); rep("csp_mlp_mm1_scatter", mm1s); rep("csp_mlp_mm2", mm2); rep("csp_scatter_add", scat)
+H, N, cnt = 24, 4352, 672
+q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
+GG = (N + 191) // 192
+ai = torch.stack([torch.randperm(N, device=dev, generator=g)[:cnt].sort().values for _ in range(H * GG)]).view(1, H, GG, cnt).to(torch.int32)
+ai = torch.cat([ai, torch.zeros(1, H, GG, N - cnt, dtype=torch.int32, device=dev)], -1).contiguous()
+ac = torch.full((1, H, GG), cnt, dtype=torch.int32, device=dev)
+o0 = torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g)
+def csp():
+    o = o0.clone()
+    torch.ops.chipmunk.csp_attn(q, k, v, o, ai, ac, 1)
+    return (o,)
+rep("csp_attn (FLUX)", csp)
+rep("dense_attn (FLUX)", lambda: torch.ops.chipmunk.dense_attn(q, k, v))
+_, l = torch.ops.chipmunk.dense_attn(q, k, v)
+rep("dense_colsum_attn (FLUX)", lambda: torch.ops.chipmunk.dense_colsum_attn(q, k, v, l))
+act = torch.randn(1, 34, F, device=dev, dtype=torch.bfloat16, generator=g)
+def topk():
+    ind = torch.empty(1, 34, F, dtype=torch.int32, device=dev); cn = torch.empty(1, 34, dtype=torch.int32, device=dev)
+    torch.ops.chipmunk.topk_indices(act, ind, cn, 0.3, 256, 0.0)
+    return ind[..., :2048].clone(), cn
+rep("topk_indices", topk)
+mask = torch.rand(1, H, GG, N, device=dev, generator=g) < 0.15
+rep("mask_to_indices", lambda: tuple(t[..., :512].clone() if t.dim() == 4 else t for t in torch.ops.chipmunk.mask_to_indices(mask, 112, 192)))
