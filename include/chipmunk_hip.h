@@ -80,7 +80,10 @@ int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64
 /* Replaces chipmunk::dense_colsum_attn (reference csrc/attn/dense_colsum_attn.cu:521-668; schema chipmunk.cpp:55).
  * p [B,H,Nq] fp32 = previous step's l.  cs [B,H,ceil(Nq/192),cs_stride] bf16:
  *   cs[b,h,g,j] = sum_{i in group g} bf16(exp(s_ij - m_i)) * bf16(exp(m_i) * p_i)   for j < Nk
- * (dense_colsum_attn.cu:267-277); columns j >= Nk are left untouched. */
+ * (dense_colsum_attn.cu:267-277); columns j >= Nk are left untouched.
+ * Launches that fill the CUs run as ONE pass (the column sums ride the dense kernel's softmax pipeline) and keep, per
+ * (device, stream), a library-owned buffer of fp32 partial sums of B*H*ceil(Nq/256)*4*Nk*4 bytes (halved per chunk of
+ * heads if that cannot be allocated); the first call on a stream allocates it, so call once before capturing a graph. */
 int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
                                const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
                                void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride, void *stream);
