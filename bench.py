@@ -19,7 +19,16 @@ Workloads (synthetic shapes, random-init weights, inputs resident in HBM before 
   behind attention), MLP sequence-parallel (118 800/N rows per rank).  Strong scaling: total work is fixed.
 * ``flux_c2`` (configs[1]): FLUX.1-dev 1280x768, 57 blocks through SparseDiffAttn + SparseDiffMlp.
 
-Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+* ``wan_c5`` (configs[4]): Wan2.1 T2V 1.3B shapes, fp8 sparse MLP + sparse attention + pinned-host caches.
+
+A HunyuanVideo "step" = per block: LayerNorm + modulation, the QKV projection (+ q/k RMSNorm), attention, the output
+projection + gated residual, LayerNorm + modulation, the MLP, gated residual (reference models.py:183-277 double-stream
+blocks 0..19, :373-431 single-stream blocks 20..59 with the fused ``linear1`` / ``linear2``).  Attention consumes synthetic
+q, k, v resident in HBM (three rotating sets); the projections run for their cost on the block's hidden state.
+
+Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.  With ``--gpus N > 1`` and no
+``WORLD_SIZE`` in the environment the script starts its own N ranks (``torch.distributed.run`` on 127.0.0.1); under an
+external ``torch.distributed.run`` it uses the ranks it is given and checks that N matches.
 """
 from __future__ import annotations
 
@@ -55,7 +64,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 hunyuan, 50 flux)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5 hunyuan, 50 flux)")
-    ap.add_argument("--workload", default="auto", choices=["auto", "hunyuan_c3", "hunyuan_sp", "flux_c2"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "hunyuan_c3", "hunyuan_sp", "flux_c2", "wan_c5"])
+    ap.add_argument("--launch-only", action="store_true",
+                    help="start the ranks, rendezvous, all-reduce once, print one JSON line with every rank's identity and exit "
+                         "(works without GPUs: gloo)")
     ap.add_argument("--layers", type=int, default=0, help="transformer blocks (default 60 HunyuanVideo / 57 FLUX.1-dev)")
     ap.add_argument("--dense-steps", type=int, default=-1, help="steps of the dense rocBLAS/SDPA comparator (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,9 +75,16 @@ def parse_args():
     ap.add_argument("--top-keys", type=float, default=None, help="hunyuan: attn.top_keys override (0.17 ~ 82 %% sparsity)")
     ap.add_argument("--no-82", action="store_true", help="hunyuan: skip the 82 %% sparsity leg")
     ap.add_argument("--offload", action="store_true", help="hunyuan: caches through pinned host memory (keep_resident_if_fits off)")
+    ap.add_argument("--sp-mode", default="heads", choices=["heads", "groups"],
+                    help="hunyuan_sp: 'heads' = the reference's head-parallel all-to-all (24/N heads per rank); 'groups' = query groups "
+                         "sharded, K/V all-gathered (the north star's split; any N)")
     ap.add_argument("--sp-chunk-heads", type=int, default=0,
-                    help="hunyuan_sp: local heads per pipeline chunk (0 = 3 when a rank has at least 6 heads -- a 3-head launch runs the "
-                         "gathered kernel 20 %% more efficiently than three 1-head ones and still leaves >= 2 chunks to overlap -- else 1)")
+                    help="hunyuan_sp: heads per pipeline chunk (0 = chosen by the cost model distributed.plan_chunks from the measured "
+                         "exchange rate and the gathered kernel's per-launch cost)")
+    ap.add_argument("--sp-chunks", default="", help="hunyuan_sp: explicit split of the heads into chunks, e.g. 1,2")
+    ap.add_argument("--no-projections", action="store_true", help="hunyuan: attention + MLP only (round-2 definition of a step)")
+    ap.add_argument("--no-legs", action="store_true", help="hunyuan: skip the 82 %%, step-caching and q-scale legs")
+    ap.add_argument("--qk-scale", type=float, default=4.0, help="hunyuan: q multiplier of the running-maximum-fallback leg")
     ap.add_argument("--sp-no-overlap", action="store_true", help="hunyuan_sp: exchange on the compute stream (reference order)")
     ap.add_argument("--sp-no-exchange", action="store_true", help="hunyuan_sp: compute only (probe for the exposed-comm fraction)")
     ap.add_argument("--grid", default="33,45,80", help="hunyuan: latent patch grid T,H,W (default 720x1280x129)")
@@ -236,20 +255,21 @@ def build_flux(dev, n_layers, timer):
 def pmc_traffic(op_name):
     """HBM bytes per launch of the op's kernels from the committed PMC runs (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; regenerate with tools/collect_pmc_traffic.py).
-    bench.py cannot collect counters itself; None if no file has the op."""
+    bench.py cannot collect counters itself (a --pmc pass is its own rocprofv3 run); returns (bytes, file) -- the file name is
+    stamped into the line as roofline.traffic_source; (None, None) if no file has the op."""
     parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
              "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
              "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"]}
     keys = parts.get(op_name, [])
-    for fname in ("r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r03_pmc_traffic.json", "r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
             continue
         with open(path) as f:
             t = json.load(f)
         if keys and all(k in t for k in keys):
-            return sum(t[k]["hbm_bytes_per_launch"] for k in keys)
-    return None
+            return sum(t[k]["hbm_bytes_per_launch"] for k in keys), "profiles/" + fname
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------------ HunyuanVideo workload
@@ -280,8 +300,100 @@ def _colsum_work(q, k, v, p):
     return work
 
 
+class HunyuanBlock:
+    """The linear algebra of one HunyuanVideo block around its attention, on `rows` token rows (sequence-parallel ranks hold
+    their own rows; weights replicated).  Double-stream blocks (reference models.py:183-277): LayerNorm + modulate -> QKV
+    projection -> q/k RMSNorm -> [attention] -> output projection + gated residual -> LayerNorm + modulate -> fc1 (tanh-GELU
+    in the GEMM epilogue) -> fc2 + gated residual.  Single-stream blocks (:373-431): ONE fused ``linear1`` (3072 -> 9216 +
+    12288), [attention], ``linear2`` over cat(attn, gelu(mlp)) (15360 -> 3072) + gated residual.  hipBLASLt GEMMs, torch
+    elementwise ops -- model code, not this library; both the sparse loop and the dense comparators run exactly this."""
+
+    def __init__(self, kind, dev, hid, ffn, heads, projections=True):
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        self.kind, self.hid, self.ffn, self.heads, self.projections = kind, hid, ffn, heads, projections
+        lin = lambda i, o: torch.nn.Linear(i, o, **bf)
+        if kind == "double" or not projections:
+            self.qkv, self.proj = (lin(hid, 3 * hid), lin(hid, hid)) if projections else (None, None)
+            self.fc1, self.fc2 = lin(hid, ffn), lin(ffn, hid)
+        else:
+            self.lin1, self.lin2 = lin(hid, 3 * hid + ffn), lin(hid + ffn, hid)
+        # shift / scale / gate vectors of the block's modulation (the model derives them from the timestep embedding)
+        self.mod = [torch.randn(hid, **bf) * 0.02 for _ in range(6)]
+        self.cat = None
+
+    @staticmethod
+    def _ln_mod(x, shift, scale):
+        xn = torch.nn.functional.layer_norm(x, (x.shape[-1],))
+        return torch.addcmul(shift, xn, 1 + scale)
+
+    def pre(self, x):
+        """Everything in front of the attention; returns what post() needs (the fused linear1 output for single blocks)."""
+        if not self.projections:
+            return None
+        hid, H = self.hid, self.heads
+        xm = self._ln_mod(x, self.mod[0], self.mod[1])
+        w = self.qkv if self.kind == "double" else self.lin1
+        h = torch.addmm(w.bias, xm, w.weight.t())
+        qk = h[:, :2 * hid].view(-1, 2 * H, hid // H)
+        torch.nn.functional.rms_norm(qk, (hid // H,))          # q / k norm: cost only, attention consumes the synthetic q, k, v
+        return h if self.kind == "single" else None
+
+    def _tokens_first(self, o, out=None):
+        """Attention output -> [rows, hid] token-major (the reference's `b h s d -> b s (h d)`); into `out` if given."""
+        if o.dim() == 4:
+            o = o[0].permute(1, 0, 2)                                  # [N, H, D] view of the head-major tensor
+            if out is None:
+                return o.reshape(o.shape[0], self.hid)
+            out.view(out.shape[0], self.heads, self.hid // self.heads).copy_(o)
+            return out
+        if out is None:
+            return o
+        out.copy_(o)
+        return out
+
+    def post(self, x, h, attn):
+        """attn: the attention output, token-major [rows, hid] or head-major [1, H, rows, D]."""
+        hid, ffn = self.hid, self.ffn
+        if not self.projections:
+            return dense_mlp(x, self.fc1, self.fc2)
+        if self.kind == "double":
+            attn_flat = self._tokens_first(attn)
+            x = torch.addcmul(x, self.mod[2], torch.addmm(self.proj.bias, attn_flat, self.proj.weight.t()))
+            xm = self._ln_mod(x, self.mod[3], self.mod[4])
+            g = torch._addmm_activation(self.fc1.bias, xm, self.fc1.weight.t(), use_gelu=True)
+            return torch.addcmul(x, self.mod[5], torch.addmm(self.fc2.bias, g, self.fc2.weight.t()))
+        if self.cat is None or self.cat.shape[0] != x.shape[0]:
+            self.cat = torch.empty(x.shape[0], hid + ffn, device=x.device, dtype=x.dtype)
+        self._tokens_first(attn, out=self.cat[:, :hid])
+        torch.ops.aten.gelu.out(h[:, 3 * hid:], approximate="tanh", out=self.cat[:, hid:])
+        return torch.addcmul(x, self.mod[2], torch.addmm(self.lin2.bias, self.cat, self.lin2.weight.t()))
+
+
+def sdpa_backend_name():
+    """Which kernel F.scaled_dot_product_attention runs for the comparator: the flash backend is forced, so the name is a
+    fact, not a guess (ROCm builds of torch carry an AOTriton and, optionally, a CK flash kernel)."""
+    lib = None
+    try:
+        lib = str(torch.backends.cuda.preferred_rocm_fa_library())
+    except Exception:
+        pass
+    return f"SDPBackend.FLASH_ATTENTION forced (torch {torch.__version__}; rocm flash library: {lib})"
+
+
+def flash_sdpa(q, k, v):
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v)
+
+
 class Hunyuan:
     """HunyuanVideo block loop on `world` ranks (world 1: everything local)."""
+
+    # gathered-kernel launch cost at HunyuanVideo size and ~93 % sparsity, ms for `h` heads of the whole sequence
+    # (tools/kbench.py: 1 head 0.91, 3 heads 2.30, 24 heads 12.7): the chunk planner's compute model
+    @staticmethod
+    def t_attn_ms(h):
+        return 0.215 + 0.695 * h if h <= 3 else 0.53 * h
 
     def __init__(self, dev, rank, world, args, timer):
         import contextlib
@@ -316,6 +428,7 @@ class Hunyuan:
                                           lambda q, k, v, o_in, indices, counts, o_scale: _csp128_work(q, k, v, indices, counts, extra=1))
         ops_pkg.dense_attn = timer.wrap("dense_attn", ops_pkg.dense_attn, _dense_work)
         ops_pkg.dense_colsum_attn = timer.wrap("dense_colsum_attn", ops_pkg.dense_colsum_attn, _colsum_work)
+        self.ops = ops_pkg
 
         self.vid = tuple(int(x) for x in args.grid.split(","))
         self.txt = 256
@@ -323,54 +436,139 @@ class Hunyuan:
         self.N = self.n_img + self.txt
         self.H, self.D, self.HID, self.FFN = 24, 128, 3072, 12288
         self.n_layers = args.layers or 60
-        assert self.H % world == 0 and self.n_img % world == 0, "head-parallel sharding needs world | 24 and world | tokens"
-        self.lh, self.ls = self.H // world, self.n_img // world
-        if args.sp_chunk_heads <= 0:
-            args.sp_chunk_heads = 3 if (self.lh >= 6 and self.lh % 3 == 0) else 2 if (self.lh >= 4 and self.lh % 2 == 0) else 1
+        self.n_double = max(1, round(self.n_layers / 3))           # 20 double-stream + 40 single-stream blocks
         H, D, N = self.H, self.D, self.N
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         bf = dict(device=dev, dtype=torch.bfloat16)
 
         self.sp = world > 1 or args.workload == "hunyuan_sp"
+        self.mode = args.sp_mode if self.sp else None
+        if self.sp and self.mode == "heads" and (H % world or self.n_img % world):
+            self.mode = "groups"                                   # 24 heads only divide by 1, 2, 3, 4, 6, 8
         self.NSETS = 3   # rotating q,k,v sets (layer l uses set l mod 3): every layer's K/V comes from HBM, not from the
         #                  256 MB Infinity Cache of the previous layer
-        if self.sp:
-            ch = args.sp_chunk_heads
-            self.n_chunks = self.lh // ch
-            self.pipe = dist_mod.HeadParallelPipeline(torch.distributed.group.WORLD if world > 1 else None, H, self.ls, self.txt, D,
-                                               torch.bfloat16, dev, chunk_heads=ch, overlap=not args.sp_no_overlap,
-                                               exchange=not args.sp_no_exchange)
-            if world > 1:
-                dist_mod.setup_dist(torch.distributed.group.WORLD, rank, world)
+        self.plan_info = None
+        group = torch.distributed.group.WORLD if world > 1 else None
+        if world > 1:
+            dist_mod.setup_dist(group, rank, world)
+        if self.sp and self.mode == "heads":
+            self.lh, self.ls = H // world, self.n_img // world
+            chunks = self._plan_chunks(dist_mod, group, self.lh)
+            self.pipe = dist_mod.HeadParallelPipeline(group, H, self.ls, self.txt, D, torch.bfloat16, dev, chunks=chunks,
+                                                      overlap=not args.sp_no_overlap, exchange=not args.sp_no_exchange)
             self.qkv_img = [torch.randn(3, 1, self.ls, H, D, generator=g, **bf) for _ in range(self.NSETS)]
             gt = torch.Generator(device=dev).manual_seed(99)   # text rows are replicated: same on every rank
             self.qkv_txt = [torch.randn(3, 1, self.txt, H, D, generator=gt, **bf) for _ in range(self.NSETS)]
-            self.rows = self.ls + (self.txt if rank == 0 else 0)
+            # the text rows' attention output is replicated by the all-gather: every rank takes txt / world of them through
+            # its projections and MLP (rank 0 also takes the remainder), so no rank carries all 256
+            tw = self.txt // world
+            self.txt_rows = (rank * tw, (rank + 1) * tw + (self.txt - tw * world if rank == world - 1 else 0))
+            self.rows = self.ls + self.txt_rows[1] - self.txt_rows[0]
+            self.group_offset = 0
+        elif self.sp:
+            rows = dist_mod.group_rows(N, world)
+            self.rows = rows[rank]
+            self.group_offset = sum(rows[:rank]) // 192
+            chunks = self._plan_chunks(dist_mod, group, H)
+            self.pipe = dist_mod.GroupParallelPipeline(group, H, rows, D, torch.bfloat16, dev, chunks=chunks,
+                                                       overlap=not args.sp_no_overlap, exchange=not args.sp_no_exchange)
+            self.qkv = [[torch.randn(1, H, self.rows, D, generator=g, **bf) for _ in range(3)] for _ in range(self.NSETS)]
         else:
-            self.n_chunks = 1
+            chunks = [H]
             self.qkv = [[torch.randn(1, H, N, D, generator=g, **bf) for _ in range(3)] for _ in range(self.NSETS)]
             self.rows = N
-        self.x = torch.randn(1, self.rows, self.HID, generator=g, **bf)
-        self.act = torch.nn.GELU(approximate="tanh")
+            self.group_offset = 0
+        self.chunks = chunks
+        self.n_chunks = len(chunks)
+        self.x = torch.randn(self.rows, self.HID, generator=g, **bf)
 
         self.layers = []
         for li in range(self.n_layers):
             layer_num, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
             if self.sp:
-                attn = [SparseDiffAttn(layer_num, cc) for cc in dist_mod.chunk_counters(counter, self.n_chunks)]
+                attn = [SparseDiffAttn(layer_num, cc, storage_slot=c, query_group_offset=self.group_offset)
+                        for c, cc in enumerate(dist_mod.chunk_counters(counter, self.n_chunks))]
             else:
                 attn = [SparseDiffAttn(layer_num, counter)]
-            fc1 = torch.nn.Linear(self.HID, self.FFN, **bf)
-            fc2 = torch.nn.Linear(self.FFN, self.HID, **bf)
-            self.layers.append((attn, fc1, fc2))
+            blk = HunyuanBlock("double" if li < self.n_double else "single", dev, self.HID, self.FFN, H, projections=not args.no_projections)
+            self.layers.append((attn, blk))
         self.counter = counter
         self.step_cache = StepCache(counter)
-        heads_per_module = args.sp_chunk_heads if self.sp else H
         t0 = time.perf_counter()
-        self.layers[0][0][0].initialize_static_mask(self.vid, self.txt, heads_per_module, dev)
+        self.layers[0][0][0].initialize_static_mask(self.vid, self.txt, max(chunks), dev)
         torch.cuda.synchronize()
         self.static_mask_s = time.perf_counter() - t0
         self.step_events = []
+        self.q_scale = 1.0
+
+    def _plan_chunks(self, dist_mod, group, heads):
+        """Split of the rank's heads into pipeline chunks: explicit (--sp-chunks / --sp-chunk-heads) or from the cost model
+        fed with the exchange rate measured on this node (one 1-head exchange, max over ranks)."""
+        args, world, dev = self.args, self.world, self.dev
+        if args.sp_chunks:
+            chunks = [int(c) for c in args.sp_chunks.split(",")]
+            assert sum(chunks) == heads, f"--sp-chunks must add up to {heads} heads"
+            return chunks
+        if args.sp_chunk_heads > 0:
+            assert heads % args.sp_chunk_heads == 0
+            return [args.sp_chunk_heads] * (heads // args.sp_chunk_heads)
+        if world == 1:
+            return [heads]
+        import torch.distributed as dist
+        D = self.D
+        if self.mode == "heads":
+            ls = self.n_img // world
+            send = torch.empty(world, ls, 1, 1, 3, D, device=dev, dtype=torch.bfloat16)
+            recv = torch.empty_like(send)
+            call = lambda: dist.all_to_all_single(recv, send, group=group)
+            scale = 1.0 / world                                            # a rank attends the whole sequence of its heads
+            t_fn = lambda h: self.t_attn_ms(h)
+        else:
+            pad = max(dist_mod.group_rows(self.N, world))
+            send = torch.empty(2, 1, 1, pad, D, device=dev, dtype=torch.bfloat16)
+            recv = torch.empty(world * 2, 1, 1, pad, D, device=dev, dtype=torch.bfloat16)
+            call = lambda: dist.all_gather_into_tensor(recv, send, group=group)
+            t_fn = lambda h: 0.215 + self.t_attn_ms(h) / world             # 1/world of every head's query groups
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            call()
+        e1.record()
+        e1.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 5], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        t_in = float(t.item())
+        t_out = t_in / 3 if self.mode == "heads" else 0.0                 # o is a third of q,k,v; groups: no outbound exchange
+        chunks = dist_mod.plan_chunks(heads, t_fn, t_in, t_out, max_chunks=8)
+        self.plan_info = {"exchange_ms_per_head_measured": round(t_in, 4), "chunks": chunks,
+                          "model_ms_per_layer": round(dist_mod.simulate_chunks(chunks, t_fn, t_in, t_out), 3),
+                          "model_ms_unchunked": round(dist_mod.simulate_chunks([heads], t_fn, t_in, t_out), 3),
+                          "model_ms_one_head_chunks": round(dist_mod.simulate_chunks([1] * heads, t_fn, t_in, t_out), 3)}
+        return chunks
+
+    # -- attention of one block -----------------------------------------------------------------------------------
+    def _attention(self, li, attn, how="sparse"):
+        """Returns the attention output token-major [rows, H*D] (sequence-parallel ranks) or head-major [1, H, N, D]."""
+        s = li % self.NSETS
+        if self.sp and self.mode == "heads":
+            o_img, o_txt = self.pipe.run(self.qkv_img[s], self.qkv_txt[s], attn)
+            return torch.cat([o_img[0], o_txt[0, self.txt_rows[0]:self.txt_rows[1]]], dim=0)
+        if self.sp:
+            q, k, v = self.qkv[s]
+            return self.pipe.run(q, k, v, attn)[0]
+        q, k, v = self.qkv[s]
+        if how == "sparse":
+            if self.q_scale != 1.0:
+                q = q * self.q_scale
+            o = attn[0](q, k, v)
+        elif how == "sdpa":
+            o = flash_sdpa(q, k, v)
+        else:                                                      # "own": this library's dense kernel
+            o = self.ops.dense_attn(q, k, v)[0]
+        return o                                                   # [1, H, N, D]: the block does the head -> token transpose
 
     # -- one denoise step: the reference's transformer loop (models.py:732-835) ---------------------------------
     def step(self, i):
@@ -386,28 +584,36 @@ class Hunyuan:
                 if kind == "full":
                     kind = "dense0" if inference_step == 0 else "mask"
                 L = len(self.layers)
-                y = None
-                for li, (attn, fc1, fc2) in enumerate(self.layers):
+                x = self.x
+                for li, (attn, blk) in enumerate(self.layers):
                     for a in attn:                                         # wait for this block's cache ...
                         if inference_step > 0 or li > 0:
                             a.storage.load_async_wait()
                     for a in self.layers[(li + 1) % L][0]:                 # ... start the next block's load
                         a.storage.load_async()
-                    if self.sp:
-                        o_img, o_txt = self.pipe.run(self.qkv_img[li % self.NSETS], self.qkv_txt[li % self.NSETS], attn)
-                    else:
-                        q, k, v = self.qkv[li % self.NSETS]
-                        attn[0](q, k, v)
-                    y = dense_mlp(self.x, fc1, fc2)
-                self.step_cache.store(y)
+                    h = blk.pre(x)
+                    o = self._attention(li, attn)
+                    x = blk.post(x, h, o)
+                self.step_cache.store(x)
             self.step_events.append((inference_step, kind, ev))
 
-    def dense_step(self):
+    def dense_step(self, how):
         with torch.no_grad():
-            for li, (attn, fc1, fc2) in enumerate(self.layers):
-                q, k, v = self.qkv[li % self.NSETS]
-                torch.nn.functional.scaled_dot_product_attention(q, k, v)
-                dense_mlp(self.x, fc1, fc2)
+            x = self.x
+            for li, (attn, blk) in enumerate(self.layers):
+                h = blk.pre(x)
+                o = self._attention(li, attn, how)
+                x = blk.post(x, h, o)
+
+    def time_dense(self, how, steps=1):
+        """1 warm step + `steps` measured steps of the all-dense schedule; seconds per step."""
+        self.dense_step(how)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.dense_step(how)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
 
     def step_times(self):
         """[(inference step, kind, seconds)] from the per-step events (each step's start to the next step's start)."""
@@ -426,30 +632,72 @@ class Hunyuan:
         _, cnt = ops_pkg.mask_to_sorted_indices(packed, a.mask_shape[0], 128, 192)
         return float(cnt.float().mean().item())
 
+    def _set_step(self, inference_step):
+        c = self.counter
+        c.cur_inference_step, c.cur_layer, c.cur_layer_submodule, c.cur_model_invocation_per_step = inference_step, 0, 0, 0
+
+    def run_steps(self, first_step, n):
+        """Run `n` inference steps from `first_step`; returns their (step, kind, seconds)."""
+        self._set_step(first_step)
+        self.step_events = []
+        for i in range(n):
+            self.step(first_step + i)
+        return self.step_times()
+
     def leg_at(self, top_keys, sparse_steps=2):
         """Re-mask every layer at another sparsity (one mask-recompute step), then time sparse steps."""
         self.cfg["attn"]["top_keys"] = top_keys
-        c = self.counter
-        c.cur_inference_step, c.cur_layer, c.cur_layer_submodule, c.cur_model_invocation_per_step = 10, 0, 0, 0
         was = self.cfg["step_caching"]["is_enabled"]
         self.cfg["step_caching"]["is_enabled"] = False
-        self.step_events = []
-        for i in range(1 + sparse_steps):
-            self.step(10 + i)
-        times = self.step_times()
+        times = self.run_steps(10, 1 + sparse_steps)
         self.cfg["step_caching"]["is_enabled"] = was
         mc = self.mean_counts()
         return {"top_keys": top_keys, "mean_kept_keys": mc, "column_sparsity": None if mc is None else 1.0 - mc / self.N,
                 "mask_step_s": times[0][2], "sparse_step_s": sum(t for _, _, t in times[1:]) / max(1, len(times) - 1)}
 
+    def step_caching_leg(self, first=12, n=9):
+        """The shipped skip schedule EXECUTED (reference models.py:732-741,834-835): inference steps 12..20 with
+        step_caching on -- 12, 16, 20 computed (sparse) and stored, 13, 14, 15, 17, 18, 19 return the stored state."""
+        was = self.cfg["step_caching"]["is_enabled"]
+        self.cfg["step_caching"]["is_enabled"] = True
+        times = self.run_steps(first, n)
+        self.cfg["step_caching"]["is_enabled"] = was
+        total = sum(t for _, _, t in times)
+        return {"inference_steps": [s for s, _, _ in times], "kinds": [k for _, k, _ in times], "seconds": round(total, 3),
+                "steps_per_s": len(times) / total, "skipped": sum(1 for _, k, _ in times if k == "skipped"),
+                "what": "measured, not projected: skipped steps cost a counter advance and return the stored hidden state"}
+
+    def qk_scale_leg(self, scale, timer, sparse_steps=2):
+        """Sparse steps with q multiplied by `scale`: 2 |q| max|k| c exceeds 64, so the gathered kernel cannot prove the fixed
+        reference point safe and runs its running-maximum fallback -- the data-dependent slow path made
+        driver-visible.  The masks are those of the unscaled run (same key counts, same work)."""
+        before = {k: list(v) for k, v in timer.records.items()}
+        timer.records = {}
+        timer.enabled = True
+        self.q_scale = scale
+        times = self.run_steps(12, sparse_steps)
+        self.q_scale = 1.0
+        timer.enabled = False
+        summ = timer.summary().get("csp_128_attn")
+        timer.records = before
+        return {"q_scale": scale, "sparse_step_s": sum(t for _, _, t in times) / len(times),
+                "csp_128_attn_avg_ms": None if summ is None else round(summ["avg_ms"], 4)}
+
+    def no_exchange_probe(self, sparse_steps=2):
+        """N > 1: sparse steps with the collectives switched off (buffers keep stale data: timing only)."""
+        was = self.pipe.exchange
+        self.pipe.exchange = False
+        times = self.run_steps(12, sparse_steps)
+        self.pipe.exchange = was
+        return sum(t for _, _, t in times) / len(times)
+
     def offload_report(self, sparse_step_s):
         """--offload: what crosses PCIe per sparse step (every block's 731 MB cache + 222 MB packed mask come back from
         pinned host memory, SURVEY 8a storage row), the rate that needs, and the measured pinned-copy rates of this box."""
-        a = next((l[0][0] for l in self.layers if l[0][0].storage.out_cache.cpu_buf[0] is not None), None)
-        if a is None:
+        mods = [a for l in self.layers for a in l[0] if a.storage.out_cache.cpu_buf[0] is not None]
+        if not mods:
             return None
-        per_layer = sum(b.numel() * b.element_size() for b in (a.storage.out_cache.cpu_buf[0], a.storage.indices.cpu_buf[0]) if b is not None)
-        n_sparse_layers = sum(1 for l in self.layers if l[0][0].storage.out_cache.cpu_buf[0] is not None)
+        per_step = sum(b.numel() * b.element_size() for a in mods for b in (a.storage.out_cache.cpu_buf[0], a.storage.indices.cpu_buf[0]) if b is not None)
         host = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
         devb = torch.empty(1 << 30, dtype=torch.uint8, device=self.dev)
         rates = {}
@@ -463,21 +711,27 @@ class Hunyuan:
             e1.record()
             e1.synchronize()
             rates[name + "_GBps"] = 4 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        return {"h2d_bytes_per_sparse_step": per_layer * n_sparse_layers, "layers_offloaded": n_sparse_layers,
-                "h2d_GBps_needed_to_hide": per_layer * n_sparse_layers / sparse_step_s / 1e9, **rates,
+        return {"h2d_bytes_per_sparse_step": per_step, "modules_offloaded": len(mods),
+                "h2d_GBps_needed_to_hide": per_step / sparse_step_s / 1e9, **rates,
                 "what": "copies ride two side streams (hipMemcpyAsync from hipHostMalloc memory), one block ahead of the compute"}
 
     def desc(self):
+        blocks = (f"{self.n_double} double-stream + {self.n_layers - self.n_double} single-stream blocks" if not self.args.no_projections
+                  else f"{self.n_layers} blocks, attention + MLP only")
         return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": HunyuanVideo 720x1280x129, {self.n_img} image + "
-                f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {self.n_layers} blocks (first 2 dense)",
+                f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {blocks} (first 2 attention layers dense)",
                 "attention": "SparseDiffAttn, configs/hunyuan_c3.yml (full steps {0,1,10,40}, top 5% + 1% random + text columns, "
-                             "bit-packed masks)", "mlp": "dense fc2(gelu_tanh(fc1(x))) per block (two hipBLASLt GEMMs, GELU in fc1's epilogue), dense as in the reference",
+                             "bit-packed masks)",
+                "block": ("LayerNorm+modulate, QKV projection (fused linear1 in single-stream blocks), q/k RMSNorm, attention, output "
+                          "projection / linear2, gated residuals, MLP with tanh-GELU -- hipBLASLt GEMMs + torch elementwise ops, dense as "
+                          "in the reference (mlp.is_enabled: false); RoPE omitted") if not self.args.no_projections else
+                         "dense fc2(gelu_tanh(fc1(x))) per block (two hipBLASLt GEMMs)",
                 "attn_top_keys": self.cfg["attn"]["top_keys"], "step_caching": bool(self.cfg["step_caching"]["is_enabled"]),
                 "caches": "pinned-host offload" if self.args.offload else "resident in HBM (offloading.keep_resident_if_fits)",
                 "static_mask_init_s": round(self.static_mask_s, 2)}
 
 
-def cpu_baseline_hunyuan(n_layers, N, n_threads=None):
+def cpu_baseline_hunyuan(n_layers, N, n_threads=None, projections=True):
     """the reference's dense eager path (F.scaled_dot_product_attention + fc2(act(fc1(x))), reference
     modules/attn.py:193-194, modules/mlp.py:33-34) with PyTorch CPU on this box's host cores, on a bounded sample
     (one head x 8 query groups against all keys; 1536 MLP rows), extrapolated to a full step.  The C oracle's dense
@@ -492,6 +746,8 @@ def cpu_baseline_hunyuan(n_layers, N, n_threads=None):
     fc2 = torch.nn.Linear(12288, 3072, dtype=torch.bfloat16)
     act = torch.nn.GELU(approximate="tanh")
     x = torch.randn(1, rows_m, 3072, generator=g).to(torch.bfloat16)
+    qkv_l = torch.nn.Linear(3072, 9216, dtype=torch.bfloat16)
+    proj_l = torch.nn.Linear(3072, 3072, dtype=torch.bfloat16)
     with torch.no_grad():
         torch.nn.functional.scaled_dot_product_attention(q[:, :, :192], k, v)   # thread pool / allocator warm-up
         t0 = time.perf_counter()
@@ -500,11 +756,13 @@ def cpu_baseline_hunyuan(n_layers, N, n_threads=None):
         fc2(act(fc1(x[:, :128])))
         t0 = time.perf_counter()
         fc2(act(fc1(x)))
+        if projections:
+            proj_l(qkv_l(x)[..., :3072])
         t_mlp = time.perf_counter() - t0
     step_s = n_layers * (24 * (N / rows_a) * t_attn + (N / rows_m) * t_mlp)
     out = {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "reference",
            "sample": f"torch CPU bf16 (reference dense eager path): SDPA of 1 head x {rows_a} queries x {N} keys in {t_attn:.2f}s + "
-                     f"{rows_m} MLP rows in {t_mlp:.2f}s, extrapolated to 24 heads x {N} rows x {n_layers} blocks (dense)",
+                     f"{rows_m} rows of MLP{' + QKV / output projection' if projections else ''} in {t_mlp:.2f}s, extrapolated to 24 heads x {N} rows x {n_layers} blocks (dense)",
            "what": "torch's CPU kernels are not reference code, but this IS the reference's CPU/eager path (SURVEY 8d)"}
     try:
         import oracle
@@ -559,13 +817,74 @@ def cpu_baseline_flux(n_layers):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def relaunch_with_ranks(args):
+    """`python bench.py --gpus N` with no rank environment: start N ranks of this script, one per GPU, on 127.0.0.1 (the
+    reference starts its ranks from one command too: Ray actors -> dist.init_process_group, examples/hunyuan/
+    sample_video.py:23-49,119-143).  Rank 0's stdout carries the ONE JSON line; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting", args.gpus, "ranks:", " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_only(rank, local_rank, world):
+    """Rendezvous + one all-reduce + one all-gather of every rank's identity; rank 0 prints one JSON line."""
+    import socket
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "host": socket.gethostname(),
+          "device": (torch.cuda.get_device_name(local_rank) + f" #{local_rank}") if use_gpu else "cpu"}
+    print("bench.py --launch-only:", json.dumps(me), file=sys.stderr)
+    ranks = [me]
+    total = rank
+    if world > 1:
+        t = torch.tensor([rank], device=dev, dtype=torch.int64)
+        dist.all_reduce(t)
+        total = int(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    assert total == world * (world - 1) // 2, "all-reduce over the ranks gave the wrong sum"
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "backend": ("nccl (RCCL)" if use_gpu else "gloo") if world > 1 else None,
+                          "rank_sum": total, "ranks": ranks}))
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_with_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus == 1:      # launched by an external torch.distributed.run without --gpus: the environment decides
+            args.gpus = world
+        else:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.launch_only:
+        return launch_only(rank, local_rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    assert torch.cuda.device_count() >= world or world == 1, f"{world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -575,23 +894,27 @@ def main():
     if args.workload == "auto":
         args.workload = "hunyuan_c3" if world == 1 else "hunyuan_sp"
     hunyuan = args.workload.startswith("hunyuan")
+    wan = args.workload == "wan_c5"
     if args.steps is None:
-        args.steps = 20 if hunyuan else 50
+        args.steps = 20 if hunyuan else 50 if not wan else 10
     if args.warmup is None:
-        args.warmup = 5 if hunyuan else 50
+        args.warmup = 5 if hunyuan else 50 if not wan else 12
     if args.dense_steps < 0:
-        args.dense_steps = 1 if hunyuan else 3
+        args.dense_steps = 1 if hunyuan else 3 if not wan else 2
 
     timer = KernelTimer()
+    wl = None
     if hunyuan:
         wl = Hunyuan(dev, rank, world, args, timer)
         step, desc = wl.step, wl.desc()
-        dense_step = (lambda i: wl.dense_step()) if not wl.sp else None
         n_layers = wl.n_layers
+    elif wan:
+        from tools.wan_workload import build_wan
+        step, dense_step, desc, wan_extra = build_wan(dev, args, timer)
+        n_layers = desc["layers"]
     else:
         n_layers = args.layers or 57
         step, dense_step, desc = build_flux(dev, n_layers, timer)
-        wl = None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -619,6 +942,7 @@ def main():
     timed_times = wl.step_times() if wl else []
 
     extra = {}
+    mean = {}
     if wl:
         # ---- what the timed region was, per step kind; projection over the reference's whole 50-step schedule
         kinds = {}
@@ -642,16 +966,20 @@ def main():
                 "seconds": round(full50, 2), "steps_per_s": 50.0 / full50,
                 "with_step_caching": {"seconds": round(cached50, 2), "steps_per_s": 50.0 / cached50}}
 
-    dense_sps = None
-    if args.dense_steps > 0 and rank == 0 and world == 1 and dense_step is not None:
-        if not hunyuan:
+    # ---- dense comparators (single GPU): the same block loop with (a) torch's flash SDPA, (b) this library's dense kernel
+    dense_sps = own_dense_sps = None
+    if args.dense_steps > 0 and rank == 0 and world == 1:
+        if wl and not wl.sp:
+            dense_sps = 1.0 / wl.time_dense("sdpa", args.dense_steps)
+            own_dense_sps = 1.0 / wl.time_dense("own", args.dense_steps)
+        elif not wl:
             dense_step(0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.dense_steps):
-            dense_step(i)
-        torch.cuda.synchronize()
-        dense_sps = args.dense_steps / (time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.dense_steps):
+                dense_step(i)
+            torch.cuda.synchronize()
+            dense_sps = args.dense_steps / (time.perf_counter() - t0)
 
     kernels = timer.summary() if rank == 0 else {}
     roof = None
@@ -662,18 +990,30 @@ def main():
         else:
             ms, flops, byts = timer.probe(name)
         achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFS, "traffic": pmc_traffic(name), "avg_launch_ms": ms,
+        traffic, traffic_source = pmc_traffic(name)
+        peak = wan_extra["peak_tflops"].get(name, MFMA_BF16_PEAK_TFS) if wan else MFMA_BF16_PEAK_TFS
+        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "avg_launch_ms": ms,
                 "launches_in_timed_region": k["launches"], "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts, "hbm_frac_at_algorithmic_bytes": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
-    if wl and not wl.sp and not args.no_82 and args.top_keys is None:
-        leg = wl.leg_at(0.17)
-        if "schedule_projection_50_steps" in extra:
-            m0 = extra["timed_steps"]["mean_step_s_by_kind (warm-up steps included)"]["dense0"]
-            tot = m0 + 3 * leg["mask_step_s"] + 46 * leg["sparse_step_s"]
-            leg["schedule_projection_50_steps"] = {"seconds": round(tot, 2), "steps_per_s": 50.0 / tot}
-        extra["sparsity_82_leg"] = leg
+    if wl and not args.no_legs:
+        if wl.sp and world > 1 and "sparse" in mean:
+            t_noex = wl.no_exchange_probe()
+            extra["exposed_comm"] = {"sparse_step_s": round(mean["sparse"], 4), "sparse_step_s_without_exchange": round(t_noex, 4),
+                                     "exposed_fraction": max(0.0, 1.0 - t_noex / mean["sparse"]),
+                                     "what": "same steps with the collectives switched off (compute + layout copies only)"}
+        if not wl.sp:
+            if "sparse" in mean:
+                extra["step_caching_leg"] = wl.step_caching_leg()
+                extra["running_max_fallback_leg"] = wl.qk_scale_leg(args.qk_scale, timer)
+            if not args.no_82 and args.top_keys is None:
+                leg = wl.leg_at(0.17)
+                if "schedule_projection_50_steps" in extra:
+                    tot = mean["dense0"] + 3 * leg["mask_step_s"] + 46 * leg["sparse_step_s"]
+                    leg["schedule_projection_50_steps"] = {"seconds": round(tot, 2), "steps_per_s": 50.0 / tot}
+                extra["sparsity_82_leg"] = leg
 
     if world > 1:
         dist.barrier()                      # nobody tears the communicator down while a peer is still timing
@@ -684,43 +1024,67 @@ def main():
         value = args.steps / elapsed
         scaling = "strong" if wl.sp else "weak"
         if wl.sp:
-            desc["parallelism"] = (f"head-parallel x{world} (attention: {wl.lh} heads/rank, all-to-all over RCCL pipelined in chunks of "
-                                   f"{args.sp_chunk_heads} head(s){'' if not args.sp_no_overlap else ', NO overlap'}); MLP sequence-parallel "
-                                   f"({wl.ls} rows/rank)")
+            if wl.mode == "heads":
+                desc["parallelism"] = (f"head-parallel x{world} (attention: {wl.lh} heads/rank, all-to-all over RCCL pipelined in head chunks "
+                                       f"{wl.chunks}{'' if not args.sp_no_overlap else ', NO overlap'}); projections + MLP sequence-parallel "
+                                       f"({wl.rows} rows on rank 0)")
+                desc["bytes_sent_per_rank_per_layer"] = wl.pipe.bytes_per_layer_sent
+            else:
+                desc["parallelism"] = (f"query-group-parallel x{world} (attention: all 24 heads of {wl.rows} query rows on rank 0, K/V "
+                                       f"all-gather over RCCL pipelined in head chunks {wl.chunks}); projections + MLP on the same rows")
+                desc["bytes_received_per_rank_per_layer"] = wl.pipe.bytes_per_layer_received
+            desc["sp_mode"] = wl.mode
             desc["dist_world_size"] = world
-            desc["bytes_sent_per_rank_per_layer"] = wl.pipe.bytes_per_layer_sent
+            desc["chunk_plan"] = wl.plan_info
             desc["exchange"] = not args.sp_no_exchange
         else:
             desc["parallelism"] = "single GPU"
     else:
         value = world * args.steps / elapsed
         scaling = "weak"
-        desc["parallelism"] = f"independent replicas x{world} (no data-path collective)"
+        desc["parallelism"] = f"independent replicas x{world} (no data-path collective)" if world > 1 else "single GPU"
+    comparator = None
+    if dense_sps is not None:
+        comparator = {"value": dense_sps, "unit": "steps/s", "sparse_over_dense": value / dense_sps,
+                      "what": "the same block loop with F.scaled_dot_product_attention: 1 warm + "
+                              f"{args.dense_steps} measured all-dense step(s)", "backend": sdpa_backend_name()}
+        if own_dense_sps is not None:
+            comparator["own_dense"] = {"value": own_dense_sps, "unit": "steps/s", "sparse_over_own_dense": value / own_dense_sps,
+                                       "what": "the same block loop with chipmunk.dense_attn (this library's dense kernel) in every layer"}
     line = {
         "metric": "DiT denoise steps/sec at fixed sparsity", "value": value, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16" if not wan else "fp8 (e4m3) MLP GEMM1 / bf16",
+        "data": "synthetic",
         "config": desc,
         "roofline": roof,
         "kernels": {n: {"launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
                         "tflops": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 1),
                         "mfma_frac": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFS, 3),
                         "share_of_kernel_time": round(k["total_ms"] / max(sum(x["total_ms"] for x in kernels.values()), 1e-9), 3),
-                        "traffic": pmc_traffic(n)} for n, k in kernels.items()},
-        "dense_gpu_comparator": None if dense_sps is None else {
-            "value": dense_sps, "unit": "steps/s", "what": "same loop, F.scaled_dot_product_attention + the same dense MLP (hipBLASLt, GELU in fc1's epilogue)",
-            "sparse_over_dense": value / dense_sps},
+                        "traffic": pmc_traffic(n)[0]} for n, k in kernels.items()},
+        "dense_gpu_comparator": comparator,
         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (
-            cpu_baseline_hunyuan(n_layers, wl.N) if hunyuan else cpu_baseline_flux(n_layers)),
+            cpu_baseline_hunyuan(n_layers, wl.N, projections=not args.no_projections) if hunyuan else
+            wan_extra["cpu_baseline"]() if wan else cpu_baseline_flux(n_layers)),
     }
+    if wan:
+        line.update(wan_extra["line"]())
     line.update(extra)
     if dense_sps is not None and "schedule_projection_50_steps" in extra:
+        def ratios(node):
+            node["sparse_over_dense"] = node["steps_per_s"] / dense_sps
+            if own_dense_sps is not None:
+                node["sparse_over_own_dense"] = node["steps_per_s"] / own_dense_sps
         p50 = extra["schedule_projection_50_steps"]
-        p50["sparse_over_dense"] = p50["steps_per_s"] / dense_sps
-        p50["with_step_caching"]["sparse_over_dense"] = p50["with_step_caching"]["steps_per_s"] / dense_sps
+        ratios(p50)
+        ratios(p50["with_step_caching"])
         if "sparsity_82_leg" in extra and "schedule_projection_50_steps" in extra["sparsity_82_leg"]:
-            q = extra["sparsity_82_leg"]["schedule_projection_50_steps"]
-            q["sparse_over_dense"] = q["steps_per_s"] / dense_sps
+            ratios(extra["sparsity_82_leg"]["schedule_projection_50_steps"])
+            leg = extra["sparsity_82_leg"]
+            leg["sparse_step_over_dense_step"] = 1.0 / dense_sps / leg["sparse_step_s"]
+            if own_dense_sps is not None:
+                leg["sparse_step_over_own_dense_step"] = 1.0 / own_dense_sps / leg["sparse_step_s"]
     print(json.dumps(line))
 
 

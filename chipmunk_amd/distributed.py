@@ -14,15 +14,14 @@ There is no all-reduce on this path.  MI355X's 8 GPUs are fully connected (7 xGM
 single hop with all 7 links busy; per layer and rank 34.2 MB (qkv) + 11.4 MB (o) go to each peer.
 
 A second sharding, not in the reference (SURVEY.md 8e option 2): ``group_parallel_attention`` shards the 192-query
-GROUPS instead of the heads and all-gathers K and V.  Same byte volume, works for any world size (24 heads only divide
-by 1, 2, 3, 4, 6, 8) and keeps every rank's work identical when heads have unequal sparsity.
+GROUPS instead of the heads and all-gathers K and V (``GroupParallelPipeline`` pipelines it over head chunks).  Works for
+any world size (24 heads only divide by 1, 2, 3, 4, 6, 8) and keeps every rank's work identical when heads have unequal
+sparsity; the output needs no exchange.  Bytes received per rank and layer: ``2 (G-1)/G s h d`` against the head-parallel
+``4 (G-1)/G s (h/G) d`` -- equal at G = 2, G/2 times more beyond (1.28 GB vs 0.32 GB at G = 8, HunyuanVideo size).
 """
 from __future__ import annotations
 
-import json
-import os
-import time
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -182,6 +181,50 @@ def chunk_counters(counter, n_chunks: int):
     return [_ChunkCounter(counter, c == n_chunks - 1) for c in range(n_chunks)]
 
 
+def simulate_chunks(chunks: Sequence[int], t_attn: Callable[[int], float], t_in_per_head: float,
+                    t_out_per_head: float) -> float:
+    """Makespan of one layer of ``HeadParallelPipeline`` for a given split of the rank's local heads: two in-order
+    resources (communication stream: in(0), in(1), out(0), in(2), out(1), ...; compute stream: attn(0), attn(1), ...),
+    attn(c) after in(c), out(c) after attn(c).  Times in any one unit."""
+    n = len(chunks)
+    comm = 0.0
+    comp = 0.0
+    in_done = [0.0] * n
+    attn_done = [0.0] * n
+    comm += chunks[0] * t_in_per_head
+    in_done[0] = comm
+    for c in range(n):
+        if c + 1 < n:
+            comm += chunks[c + 1] * t_in_per_head
+            in_done[c + 1] = comm
+        comp = max(comp, in_done[c]) + t_attn(chunks[c])
+        attn_done[c] = comp
+        comm = max(comm, attn_done[c]) + chunks[c] * t_out_per_head
+    return max(comm, comp)
+
+
+def plan_chunks(local_heads: int, t_attn: Callable[[int], float], t_in_per_head: float, t_out_per_head: float,
+                max_chunks: int = 6) -> List[int]:
+    """Split of ``local_heads`` into pipeline chunks with the smallest simulated makespan.  Candidates: every uniform
+    split, and "small first / small last" splits (a short first chunk shortens the exposed inbound exchange, the large
+    middle launches run the gathered kernel at its better multi-head efficiency).  A 1-head gathered launch costs
+    0.91 ms against 2.30 ms for 3 heads at HunyuanVideo size, so finer is not always better."""
+    cands = []
+    for ch in range(1, local_heads + 1):
+        if local_heads % ch == 0 and local_heads // ch <= max(max_chunks, 1):
+            cands.append([ch] * (local_heads // ch))
+    for first in range(1, local_heads):
+        rest = local_heads - first
+        cands.append([first, rest])
+        for last in range(1, rest):
+            cands.append([first, rest - last, last])
+        for ch in range(1, rest):
+            if rest % ch == 0 and 1 + rest // ch <= max_chunks:
+                cands.append([first] + [ch] * (rest // ch))
+    best = min(cands, key=lambda c: (simulate_chunks(c, t_attn, t_in_per_head, t_out_per_head), len(c)))
+    return best
+
+
 class HeadParallelPipeline:
     """Head-parallel exchange of one attention layer, pipelined over chunks of the rank's local heads.
 
@@ -193,35 +236,48 @@ class HeadParallelPipeline:
     real model's (nothing is prefetched across layers).  xGMI is point to point: every all-to-all is a single hop with all
     7 links of the GPU busy; per chunk and rank ``3 * ls * d * 2`` bytes go to each peer.
 
+    ``chunks``: heads per chunk (any split of ``lh``, see ``plan_chunks``); ``chunk_heads`` = the uniform split.
+
     All exchange buffers are allocated once (no allocator traffic across streams).  Works without a process group
     (world 1: the exchange degenerates to the layout change) and on CPU tensors (gloo; no streams) for the tests.
 
-    ``attn_chunks[c](q, k, v) -> o``: attention of chunk ``c`` over ``[b, ch, s_img + s_txt, d]`` tensors.
+    ``attn_chunks[c](q, k, v) -> o``: attention of chunk ``c`` over ``[b, ch_c, s_img + s_txt, d]`` tensors.
+
+    Aliasing contract: ``run`` returns views of buffers this object owns (``out_img``, and without an exchange
+    ``out_txt_local``); the next ``run`` overwrites them.  A caller that keeps a layer's output past the next layer must
+    copy it (``copy_outputs=True`` returns fresh tensors, as the reference's ``collect_heads`` does).
     """
 
     def __init__(self, group, heads: int, ls: int, txt_len: int, d: int, dtype: torch.dtype, device: torch.device,
-                 chunk_heads: int = 1, batch: int = 1, overlap: bool = True, exchange: bool = True):
+                 chunk_heads: int = 1, batch: int = 1, overlap: bool = True, exchange: bool = True,
+                 chunks: Optional[Sequence[int]] = None, copy_outputs: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
-        assert heads % self.world == 0, "the head count must divide by the world size (use group_parallel_attention otherwise)"
+        assert heads % self.world == 0, "the head count must divide by the world size (use GroupParallelPipeline otherwise)"
         self.h, self.lh, self.ls, self.txt, self.d, self.b = heads, heads // self.world, ls, txt_len, d, batch
-        assert self.lh % chunk_heads == 0
-        self.ch = chunk_heads
-        self.n_chunks = self.lh // chunk_heads
+        if chunks is None:
+            assert self.lh % chunk_heads == 0
+            chunks = [chunk_heads] * (self.lh // chunk_heads)
+        self.chunks = [int(c) for c in chunks]
+        assert sum(self.chunks) == self.lh and all(c > 0 for c in self.chunks), "chunks must partition the local heads"
+        self.offsets = [sum(self.chunks[:c]) for c in range(len(self.chunks))]
+        self.ch = self.chunks[0]
+        self.n_chunks = len(self.chunks)
         self.s_img = ls * self.world
         self.exchange = exchange and self.world > 1     # exchange=False: compute-only probe (measures exposed comm)
         self.is_cuda = device.type == "cuda"
         self.overlap = overlap and self.is_cuda
+        self.copy_outputs = copy_outputs
         self.comm_stream = torch.cuda.Stream(device) if self.overlap else None
-        G, ch = self.world, self.ch
+        G = self.world
         mk = lambda *shape: torch.empty(*shape, dtype=dtype, device=device)
         # per chunk: send/recv slabs [G, ls, ch, b, 3, d]; the attention inputs [3, b, ch, s_img + txt, d]
-        self.send_in = [mk(G, ls, ch, batch, 3, d) for _ in range(self.n_chunks)]
-        self.recv_in = [mk(G, ls, ch, batch, 3, d) for _ in range(self.n_chunks)]
-        self.qkv = [mk(3, batch, ch, self.s_img + txt_len, d) for _ in range(self.n_chunks)]
-        self.send_out = [mk(G, ch, ls, batch, d) for _ in range(self.n_chunks)]
-        self.recv_out = [mk(G, ch, ls, batch, d) for _ in range(self.n_chunks)]
+        self.send_in = [mk(G, ls, ch, batch, 3, d) for ch in self.chunks]
+        self.recv_in = [mk(G, ls, ch, batch, 3, d) for ch in self.chunks]
+        self.qkv = [mk(3, batch, ch, self.s_img + txt_len, d) for ch in self.chunks]
+        self.send_out = [mk(G, ch, ls, batch, d) for ch in self.chunks]
+        self.recv_out = [mk(G, ch, ls, batch, d) for ch in self.chunks]
         self.out_img = mk(batch, ls, heads, d)
         self.out_txt_local = mk(batch, self.lh, txt_len, d)
         self.bytes_per_layer_sent = (G - 1) * ls * self.lh * batch * 4 * d * self.send_in[0].element_size() if G > 1 else 0
@@ -238,24 +294,24 @@ class HeadParallelPipeline:
 
     def _inbound(self, c: int, qkv_img: torch.Tensor, qkv_txt: torch.Tensor) -> None:
         """qkv_img [3, b, ls, h, d] (local tokens, all heads), qkv_txt [3, b, txt, h, d] -> self.qkv[c]."""
-        G, ch, lh, ls, b, d = self.world, self.ch, self.lh, self.ls, self.b, self.d
-        # heads r*lh + c*ch .. + ch of every destination rank r
-        src = qkv_img.reshape(3, b, ls, G, lh, d)[:, :, :, :, c * ch:(c + 1) * ch]           # [3, b, ls, G, ch, d]
+        G, ch, off, lh, ls, b, d = self.world, self.chunks[c], self.offsets[c], self.lh, self.ls, self.b, self.d
+        # heads r*lh + off .. + ch of every destination rank r
+        src = qkv_img.reshape(3, b, ls, G, lh, d)[:, :, :, :, off:off + ch]                   # [3, b, ls, G, ch, d]
         self.send_in[c].copy_(src.permute(3, 2, 4, 1, 0, 5))
         self._a2a(self.recv_in[c], self.send_in[c])
         dst = self.qkv[c][:, :, :, :self.s_img].reshape(3, b, ch, G, ls, d)
         dst.copy_(self.recv_in[c].permute(4, 3, 2, 0, 1, 5))                                  # [3, b, ch, G(src), ls, d]
-        h0 = self.rank * lh + c * ch
+        h0 = self.rank * lh + off
         self.qkv[c][:, :, :, self.s_img:].copy_(qkv_txt[:, :, :, h0:h0 + ch].permute(0, 1, 3, 2, 4))
 
     def _outbound(self, c: int, o: torch.Tensor) -> None:
-        """o [b, ch, s_img + txt, d] -> image rows back to token sharding (heads r*lh + c*ch.. of source rank r)."""
-        G, ch, lh, ls, b, d = self.world, self.ch, self.lh, self.ls, self.b, self.d
+        """o [b, ch, s_img + txt, d] -> image rows back to token sharding (heads r*lh + off.. of source rank r)."""
+        G, ch, off, lh, ls, b, d = self.world, self.chunks[c], self.offsets[c], self.lh, self.ls, self.b, self.d
         self.send_out[c].copy_(o[:, :, :self.s_img].reshape(b, ch, G, ls, d).permute(2, 1, 3, 0, 4))
         self._a2a(self.recv_out[c], self.send_out[c])
-        dst = self.out_img.reshape(b, ls, G, lh, d)[:, :, :, c * ch:(c + 1) * ch]             # [b, ls, G, ch, d]
+        dst = self.out_img.reshape(b, ls, G, lh, d)[:, :, :, off:off + ch]                    # [b, ls, G, ch, d]
         dst.copy_(self.recv_out[c].permute(3, 2, 0, 1, 4))
-        self.out_txt_local[:, c * ch:(c + 1) * ch].copy_(o[:, :, self.s_img:])
+        self.out_txt_local[:, off:off + ch].copy_(o[:, :, self.s_img:])
 
     @torch.compiler.disable
     def run(self, qkv_img: torch.Tensor, qkv_txt: torch.Tensor, attn_chunks) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -305,4 +361,107 @@ class HeadParallelPipeline:
             o_txt = o_txt.permute(0, 2, 1, 3).reshape(b, self.txt, self.lh * self.d)
             if self.world > 1:
                 o_txt = o_txt.repeat(1, 1, self.world)
-        return self.out_img.reshape(b, self.ls, self.h * self.d), o_txt
+        o_img = self.out_img.reshape(b, self.ls, self.h * self.d)
+        if self.copy_outputs:
+            o_img = o_img.clone()
+        return o_img, o_txt
+
+
+def group_rows(n_tokens: int, world: int, group: int = 192) -> List[int]:
+    """Rows of the full sequence each rank owns under query-group sharding: whole 192-row groups, dealt evenly, the
+    ragged last group on the last rank (HunyuanVideo: 621 groups -> 78 x 7 + 75 groups at 8 ranks)."""
+    n_groups = (n_tokens + group - 1) // group
+    per = (n_groups + world - 1) // world
+    rows = []
+    for r in range(world):
+        lo = min(r * per * group, n_tokens)
+        hi = min((r + 1) * per * group, n_tokens)
+        rows.append(hi - lo)
+    return rows
+
+
+class GroupParallelPipeline:
+    """Query-group sharding of one attention layer (the north star's K/V all-gather split), pipelined over head chunks.
+
+    Rank r owns ``rows[r]`` consecutive rows of the sequence (whole 192-query groups, ``group_rows``) for ALL heads -- the
+    same rows its sequence-parallel MLP owns, so the attention output needs no exchange.  K and V of the other ranks' rows
+    are all-gathered; chunk ``c + 1``'s all-gather runs on a side stream while chunk ``c`` attends.  The sparse state (mask
+    rows, ``l``, output cache) of a query group lives on the rank that owns the group.
+
+    ``attn_chunks[c](q [b, ch, rows_r, d], k [b, ch, n, d], v [b, ch, n, d]) -> o [b, ch, rows_r, d]``.
+    ``run(q, k, v)`` takes the rank's rows ``[b, h, rows_r, d]`` and returns ``o [b, rows_r, h*d]`` (a view of a buffer
+    this object owns, overwritten by the next call).
+    """
+
+    def __init__(self, group, heads: int, rows: Sequence[int], d: int, dtype: torch.dtype, device: torch.device,
+                 chunks: Optional[Sequence[int]] = None, batch: int = 1, overlap: bool = True, exchange: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.rank = dist.get_rank(group) if group is not None else 0
+        assert len(rows) == self.world
+        self.rows = [int(r) for r in rows]
+        self.n = sum(self.rows)
+        self.pad = max(self.rows)                        # all-gather slabs are equal-sized; short ranks pad
+        self.my_rows = self.rows[self.rank]
+        self.h, self.d, self.b = heads, d, batch
+        self.chunks = [int(c) for c in (chunks or [heads])]
+        assert sum(self.chunks) == heads
+        self.offsets = [sum(self.chunks[:c]) for c in range(len(self.chunks))]
+        self.n_chunks = len(self.chunks)
+        self.exchange = exchange and self.world > 1
+        self.is_cuda = device.type == "cuda"
+        self.overlap = overlap and self.is_cuda
+        self.comm_stream = torch.cuda.Stream(device) if self.overlap else None
+        mk = lambda *shape: torch.empty(*shape, dtype=dtype, device=device)
+        G = self.world
+        self.send = [mk(2, batch, ch, self.pad, d) for ch in self.chunks]
+        self.recv = [mk(G, 2, batch, ch, self.pad, d) for ch in self.chunks]
+        self.kv = [mk(2, batch, ch, self.n, d) for ch in self.chunks]
+        self.out = mk(batch, self.my_rows, heads, d)
+        esz = self.send[0].element_size()
+        self.bytes_per_layer_received = (G - 1) * 2 * batch * heads * self.pad * d * esz if G > 1 else 0
+
+    def _stream(self, s):
+        return torch.cuda.stream(s) if s is not None else _NullCtx()
+
+    def _gather(self, c: int, k: torch.Tensor, v: torch.Tensor) -> None:
+        ch, off, r = self.chunks[c], self.offsets[c], self.my_rows
+        self.send[c][0, :, :, :r].copy_(k[:, off:off + ch])
+        self.send[c][1, :, :, :r].copy_(v[:, off:off + ch])
+        if self.exchange:
+            # concatenation form (dim 0 = G * 2): the layout every backend accepts
+            dist.all_gather_into_tensor(self.recv[c].view(-1, *self.recv[c].shape[2:]), self.send[c], group=self.group)
+        elif self.world == 1:
+            self.recv[c][0].copy_(self.send[c])
+        lo = 0
+        for g, rows_g in enumerate(self.rows):           # [G, 2, b, ch, pad, d] -> [2, b, ch, n, d] (drop the padding)
+            self.kv[c][:, :, :, lo:lo + rows_g].copy_(self.recv[c][g, :, :, :, :rows_g])
+            lo += rows_g
+
+    @torch.compiler.disable
+    def run(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_chunks) -> torch.Tensor:
+        assert len(attn_chunks) == self.n_chunks and q.shape[-2] == self.my_rows
+        comm = self.comm_stream
+        cur = torch.cuda.current_stream() if self.is_cuda else None
+        if comm is not None:
+            comm.wait_stream(cur)
+        ev = [None] * self.n_chunks
+
+        def gather(c):
+            with self._stream(comm):
+                self._gather(c, k, v)
+                if comm is not None:
+                    ev[c] = comm.record_event()
+
+        gather(0)
+        for c in range(self.n_chunks):
+            if c + 1 < self.n_chunks:
+                gather(c + 1)
+            if comm is not None:
+                cur.wait_event(ev[c])
+            ch, off = self.chunks[c], self.offsets[c]
+            o = attn_chunks[c](q[:, off:off + ch], self.kv[c][0], self.kv[c][1])
+            self.out[:, :, off:off + ch].copy_(o.permute(0, 2, 1, 3))
+        if comm is not None:
+            cur.wait_stream(comm)     # the next layer's gathers reuse the slabs only after this layer's readers
+        return self.out.reshape(self.b, self.my_rows, self.h * self.d)

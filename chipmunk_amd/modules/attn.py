@@ -25,7 +25,7 @@ from torch import Tensor, nn
 
 from .. import ops
 from ..ops.voxel import get_local_indices_with_text
-from ..util.config import GLOBAL_CONFIG
+from ..util.config import GLOBAL_CONFIG, amd_key
 from ..util.layer_counter import LayerCounter
 from ..util.storage import AttnStorage
 
@@ -39,11 +39,16 @@ def _cdiv(a: int, b: int) -> int:
 
 
 class SparseDiffAttn(nn.Module):
-    def __init__(self, layer_num: int, layer_counter: LayerCounter):
+    def __init__(self, layer_num: int, layer_counter: LayerCounter, storage_slot: int = 0, query_group_offset: int = 0):
+        """``storage_slot``: several modules may serve ONE layer (head chunks of a sequence-parallel rank,
+        ``distributed.chunk_counters``); each needs its own device slot in the offload pipeline.  ``query_group_offset``:
+        first 192-row query group this module sees (query-group sharding: q holds a slice of the sequence's rows, k / v
+        the whole sequence); selects the rows of the shared static mask."""
         super().__init__()
         self.layer_num = layer_num
         self.layer_counter = layer_counter
-        self.storage = AttnStorage(layer_num, init_names=["indices", "out_cache"])
+        self.query_group_offset = query_group_offset
+        self.storage = AttnStorage(layer_num, init_names=["indices", "out_cache"], slot=storage_slot)
         self.mask_shape = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
 
     # ------------------------------------------------------------------------------------------ static mask
@@ -68,20 +73,27 @@ class SparseDiffAttn(nn.Module):
         singleton_static_mask = mask
         singleton_video_query_groups = sparse_groups
 
+    def _static(self, heads: int, qg: int, n: int):
+        """(static mask, sparse-group flags) for this module's heads and query groups.  The shared tensors hold
+        ``local_heads_num`` identical head planes (reference attn.py:67); a module serving fewer heads takes a prefix."""
+        g0 = self.query_group_offset
+        h = min(heads, singleton_static_mask.shape[1])
+        return (singleton_static_mask[:, :h, g0:g0 + qg, :n], singleton_video_query_groups[:, :h, g0:g0 + qg, :])
+
     def random_and_topk(self, cs: Tensor, topk: int) -> Tensor:
         """1% random keys + top-k column sums, limited to the groups that are sparse at all, plus the static mask."""
         cfg = GLOBAL_CONFIG["attn"]
         qg, n = cs.shape[-2], cs.shape[-1]
-        if cs.is_cuda and cfg.get("fused_topk_mask", True) and cs.dtype == torch.bfloat16 and n <= 122880:
+        static, groups = self._static(cs.shape[1], qg, n)
+        if cs.is_cuda and amd_key("attn", "fused_topk_mask") and cs.dtype == torch.bfloat16 and n <= 122880:
             # one kernel for the whole chain below (the random 1 % comes from a counter-based hash, not torch's RNG)
-            return ops.topk_mask(cs, topk, 0.01, singleton_video_query_groups[..., :qg, :],
-                                 singleton_static_mask[..., :qg, :n])
+            return ops.topk_mask(cs, topk, 0.01, groups, static)
         mask = torch.randint(0, 100, cs.shape, device=cs.device, dtype=torch.uint8) == 0
         mask.scatter_(-1, cs.topk(k=topk, dim=-1).indices, True)
         # (mask * groups) | static of the reference (modules/attn.py:76-82) as in-place logical ops on the fresh mask: same
         # booleans, no bool x bool product kernel and no two 1.8 GB temporaries at HunyuanVideo size (16 -> 3 ms)
-        mask.logical_and_(singleton_video_query_groups[..., :qg, :n])
-        mask.logical_or_(singleton_static_mask[..., :qg, :n])
+        mask.logical_and_(groups)
+        mask.logical_or_(static)
         return mask
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -90,8 +102,8 @@ class SparseDiffAttn(nn.Module):
         if cfg["should_compress_indices"]:
             packed = self.storage.get_indices()
             shape = self.mask_shape[self.layer_counter.cur_model_invocation_per_step]
-            if cfg.get("fused_packed_mask_to_indices", True) and packed.is_cuda and shape[-1] % 8 == 0:
-                if cfg.get("sorted_indices", True):
+            if amd_key("attn", "fused_packed_mask_to_indices") and packed.is_cuda and shape[-1] % 8 == 0:
+                if amd_key("attn", "sorted_indices"):
                     return ops.mask_to_sorted_indices(packed, shape, multiple_of, bm)
                 return ops.packed_mask_to_indices(packed, shape, multiple_of, bm)
             return ops.mask_to_indices(ops.bitunpack(packed, shape), multiple_of, bm)
@@ -129,11 +141,11 @@ class SparseDiffAttn(nn.Module):
                     if tk > 0:
                         mask = self.random_and_topk(bs, tk)
                     else:
-                        mask = singleton_static_mask[..., :bs.shape[-2], :bs.shape[-1]]
+                        mask = self._static(bs.shape[1], bs.shape[-2], bs.shape[-1])[0]
                     packed, mask_shape = ops.bitpack(mask)
                     self.mask_shape[self.layer_counter.cur_model_invocation_per_step] = mask_shape
                     self.storage.set_indices(packed)
-                    if mask.is_cuda and cfg.get("fused_packed_mask_to_indices", True) and cfg.get("sorted_indices", True):
+                    if mask.is_cuda and amd_key("attn", "fused_packed_mask_to_indices") and amd_key("attn", "sorted_indices"):
                         inds, counts = ops.mask_to_sorted_indices(mask, mask.shape, multiple_of, bm)
                     else:
                         inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
@@ -153,7 +165,7 @@ class SparseDiffAttn(nn.Module):
             if not cfg["recompute_mask"]:
                 inds, counts = self._stored_indices(multiple_of, bm)
 
-            if o.is_cuda and cfg.get("fused_residual", True):
+            if o.is_cuda and amd_key("attn", "fused_residual"):
                 # dense - sparse in the attention kernel's epilogue (bf16(o - bf16(sparse)), the same two roundings as the
                 # reference's `o - csp_attn(...)`), no 731 MB intermediate at HunyuanVideo size
                 o_cache = ops.csp_attn_out(q, k, v, o, inds, counts, -1)
@@ -169,14 +181,14 @@ class SparseDiffAttn(nn.Module):
         inds, counts = self._stored_indices(multiple_of, bm)
         o = self.storage.get_out_cache()
         if do_padding:
-            if o.is_cuda and cfg.get("fused_residual", True):
+            if o.is_cuda and amd_key("attn", "fused_residual"):
                 return ops.csp_attn_out(q, k, v, o, inds, counts, 1)   # cache + delta in one kernel; the cache is only read
             return o + ops.csp_attn(q, k, v, inds, counts)
         # Is `o` the persistent cache itself, or a pipeline slot that the next load overwrites from the host copy?  The
         # reference decides on the config flag (attn.py:186-188) because there a flagged tensor always lives on the host;
         # here a flagged tensor may stay resident (offloading.keep_resident_if_fits), so ask the storage.
         persistent = self.storage.out_cache.is_resident()
-        if o.is_cuda and cfg.get("fused_residual", True) and persistent:
+        if o.is_cuda and amd_key("attn", "fused_residual") and persistent:
             return ops.csp_attn_out(q, k, v, o, inds, counts, 1)  # cache + delta in one kernel, cache untouched
         if persistent:
             o = o.clone()  # the kernel accumulates in place and the cache must survive (reference attn.py:186-188)

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from .. import ops
-from ..util.config import GLOBAL_CONFIG
+from ..util.config import GLOBAL_CONFIG, amd_key
 from ..util.layer_counter import LayerCounter
 from ..util.storage import MlpStorage
 
@@ -70,7 +70,7 @@ class SparseDiffMlp:
             bmfc1 = fc1(block_mean(x, mbm))
             r = bm // mbm
             cache = self.storage.get_blockmean_mid_cache()
-            if r == 1 and bmfc1.is_cuda and cfg.get("fused_topk_delta", True) and bmfc1.is_contiguous():
+            if r == 1 and bmfc1.is_cuda and amd_key("mlp", "fused_topk_delta") and bmfc1.is_contiguous():
                 # one kernel for |bmfc1 - cache| -> top-k indices -> copy of the selected columns into the cache
                 inds = torch.empty_like(bmfc1, dtype=torch.int32)
                 counts = torch.empty((bmfc1.size(0), bmfc1.size(1)), dtype=torch.int32, device=x.device)

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from ..util.config import GLOBAL_CONFIG
+from ..util.config import GLOBAL_CONFIG, amd_key
 from .indexed_io import scatter_add
 
 USE_FUSED_MLP_MATMUL_2 = True
@@ -98,7 +98,7 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
     assert K2 == K2_, "K2 must match"
     sparse_act_packed = torch.empty((M, K2), device=x.device, dtype=sparse_act_T.dtype)  # bf16 also when x is fp8
     if (x.is_cuda and fc1w.dtype == torch.bfloat16
-            and GLOBAL_CONFIG["mlp"].get("fused_scatter", True)):
+            and amd_key("mlp", "fused_scatter")):
         # GEMM1 applies the scatter-add of its own deltas (same bits as the two-kernel form), GEMM2 runs alone
         mm1_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
         csp_mlp_mm2(sparse_act_packed, fc2w_T, indices, counts, cached_out)

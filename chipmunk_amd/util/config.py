@@ -102,6 +102,13 @@ BASE_CONFIG["mlp"]["fused_scatter"] = AMD_EXTRA_KEYS["mlp.fused_scatter"]
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
 
 
+def amd_key(section: str, key: str) -> Any:
+    """Value of one of the ``AMD_EXTRA_KEYS``: the live config if it has the key, otherwise the ONE default written
+    above (a section dict copied from the reference does not carry these keys; it then gets the documented defaults --
+    residency off, fused paths on -- instead of a KeyError or a second set of fallbacks scattered over the modules)."""
+    return GLOBAL_CONFIG.get(section, {}).get(key, AMD_EXTRA_KEYS[f"{section}.{key}"])
+
+
 def update_global_config(config: Dict[str, Any]) -> None:
     """Shallow top-level update (reference config.py:81-86)."""
     GLOBAL_CONFIG.update(config)

@@ -21,8 +21,9 @@ class _NamedStorage:
     _async_fields: List[str] = []     # fields touched by load_async / load_async_wait (reference order)
     _complete_fields: List[str] = []  # fields advanced by complete_cur_layer
 
-    def __init__(self, layer_num: int):
+    def __init__(self, layer_num: int, slot: int = 0):
         self.layer_num = layer_num
+        self.slot = slot          # device-slot namespace: modules that serve the same layer must not share load slots
         for field in self._fields:
             setattr(self, field, None)
 
@@ -33,7 +34,8 @@ class _NamedStorage:
     def _set(self, field: str, value: Tensor) -> None:
         holder = getattr(self, field)
         if holder is None:
-            holder = MaybeOffloadedTensor(f"{self._prefix}.{field}", self.layer_num, value.dtype, value.device)
+            holder = MaybeOffloadedTensor(f"{self._prefix}.{field}", self.layer_num, value.dtype, value.device,
+                                          slot=self.slot)
             setattr(self, field, holder)
         holder.offload(value)
 
@@ -84,15 +86,15 @@ class AttnStorage(_NamedStorage):
     _async_fields = ["indices", "counts", "out_cache", "lse_constants"]
     _complete_fields = ["indices", "counts", "out_cache", "lse_constants"]
 
-    def __init__(self, layer_num: int, init_names: List[str] = ()):
-        super().__init__(layer_num)
+    def __init__(self, layer_num: int, init_names: List[str] = (), slot: int = 0):
+        super().__init__(layer_num, slot)
         # eager creation with the dtypes the attention module stores (reference layer_storage.py:107-121)
         if "out_cache" in init_names:
             self.out_cache = MaybeOffloadedTensor("attn.out_cache", layer_num, torch.bfloat16, torch.device("cuda"),
-                                                  cpu_buf_size=MaybeOffloadedTensor.LARGE_BUF_SIZE)
+                                                  cpu_buf_size=MaybeOffloadedTensor.LARGE_BUF_SIZE, slot=slot)
         if "indices" in init_names:
             self.indices = MaybeOffloadedTensor("attn.indices", layer_num, torch.uint8, torch.device("cuda"),
-                                                cpu_buf_size=MaybeOffloadedTensor.MEDIUM_BUF_SIZE)
+                                                cpu_buf_size=MaybeOffloadedTensor.MEDIUM_BUF_SIZE, slot=slot)
 
 
 class LayerStorage:

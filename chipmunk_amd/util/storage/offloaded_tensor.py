@@ -17,14 +17,15 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ..config import GLOBAL_CONFIG
+from ..config import GLOBAL_CONFIG, amd_key
 
 # how many layers' worth of device slots exist per tensor name (reference :5)
 PIPELINE_DEPTH = 2
 assert PIPELINE_DEPTH > 1, "a pipeline depth of 1 would serialise every layer behind its own host copy"
 
 _streams: Dict[str, "torch.cuda.Stream"] = {}
-# device slots shared by all layers: gpu_tensors[name][layer % PIPELINE_DEPTH]
+# device slots shared by all layers: gpu_tensors[name][layer % PIPELINE_DEPTH]; modules that serve the SAME layer (head
+# chunks of a sequence-parallel rank) get their own slot set under the key "name#slot"
 gpu_tensors: Dict[str, List[Optional[torch.Tensor]]] = {}
 _resident_bytes = 0
 
@@ -52,11 +53,12 @@ class MaybeOffloadedTensor:
 
     @torch.compiler.disable
     def __init__(self, name: str, layer_num: int, dtype: torch.dtype, device: torch.device,
-                 cpu_buf_size: int = LARGE_BUF_SIZE):
+                 cpu_buf_size: int = LARGE_BUF_SIZE, slot: int = 0):
         flags = GLOBAL_CONFIG["offloading"]
         if name not in flags:
             raise ValueError(f"Invalid tensor name: {name}. Expected one of: {flags.keys()}")
         self.name = name
+        self.slot_name = name if slot == 0 else f"{name}#{slot}"
         self.layer_num = layer_num
         self.layer_key = layer_num % PIPELINE_DEPTH
         self.dtype = dtype
@@ -68,8 +70,8 @@ class MaybeOffloadedTensor:
         self.real_shape: List[Optional[torch.Size]] = [None] * n_inv
         self._resident: List[bool] = [False] * n_inv
         self.model_invocation_count = 0
-        if name not in gpu_tensors:
-            gpu_tensors[name] = [None] * PIPELINE_DEPTH
+        if self.slot_name not in gpu_tensors:
+            gpu_tensors[self.slot_name] = [None] * PIPELINE_DEPTH
 
     # -- bookkeeping -------------------------------------------------------------------------------------------
     def complete_cur_layer(self) -> None:
@@ -84,9 +86,8 @@ class MaybeOffloadedTensor:
             return True
         if self._resident[key]:
             return True
-        flags = GLOBAL_CONFIG["offloading"]
-        if flags.get("keep_resident_if_fits", False):
-            if _resident_bytes + nbytes <= float(flags.get("hbm_budget_gb", 0.0)) * (1 << 30):
+        if amd_key("offloading", "keep_resident_if_fits"):
+            if _resident_bytes + nbytes <= float(amd_key("offloading", "hbm_budget_gb")) * (1 << 30):
                 _resident_bytes += nbytes
                 self._resident[key] = True
                 return True
@@ -125,7 +126,7 @@ class MaybeOffloadedTensor:
     def get_loaded_value(self) -> Optional[torch.Tensor]:
         if self._is_resident_now():
             return self.gpu_tensor[self.get_cur_model_invocation_key()]
-        slot = gpu_tensors[self.name][self.layer_key]
+        slot = gpu_tensors[self.slot_name][self.layer_key]
         assert slot is not None, (
             f"Tensor {self.name} is not loaded yet for layer {self.layer_num}. "
             "Please call load_async() first (followed by load_async_wait())")
@@ -139,10 +140,10 @@ class MaybeOffloadedTensor:
             return None
         if self._is_resident_now():
             return self.gpu_tensor[key]
-        slot = gpu_tensors[self.name][self.layer_key]
+        slot = gpu_tensors[self.slot_name][self.layer_key]
         if slot is None or slot.shape != shape or slot.dtype != self.cpu_buf[key].dtype:
             slot = torch.empty(shape, dtype=self.cpu_buf[key].dtype, device=self.device)
-            gpu_tensors[self.name][self.layer_key] = slot
+            gpu_tensors[self.slot_name][self.layer_key] = slot
         side = load_stream()
         side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
         with torch.cuda.stream(side):

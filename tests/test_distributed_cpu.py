@@ -87,6 +87,36 @@ def _worker(rank, world, port, ret):
                 torch.testing.assert_close(o_txt, ref2[:, s_img:].reshape(b, s_txt, a2 * d), rtol=1e-5, atol=1e-5)
             assert seen[0] == (0, (b, ch, s_img + s_txt, d)) and len(seen) == 2 * (lh2 // ch)
             assert pipe.bytes_per_layer_sent == (world - 1) * ls * lh2 * b * 4 * d * 4
+        # uneven chunks (what plan_chunks may pick: a short first chunk) give the same result
+        pipe = D.HeadParallelPipeline(dist.group.WORLD, a2, ls, s_txt, d, torch.float32, torch.device("cpu"), chunks=[1, 3])
+        shapes = []
+
+        def attn_u(q, k, v):
+            shapes.append(q.shape[1])
+            return F.scaled_dot_product_attention(q, k, v)
+        o_img, o_txt = pipe.run(img_full[:, :, rank * ls:(rank + 1) * ls].contiguous(), txt_full, [attn_u, attn_u])
+        assert shapes == [1, 3]
+        torch.testing.assert_close(o_img, ref2[:, rank * ls:(rank + 1) * ls].reshape(b, ls, a2 * d), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(o_txt, ref2[:, s_img:].reshape(b, s_txt, a2 * d), rtol=1e-5, atol=1e-5)
+
+        # ---- query-group sharding pipelined over head chunks, uneven rows per rank (whole "groups" of 4 rows here)
+        n_tok = s_img + s_txt                                                    # 30 rows: ranks own 16 and 14
+        rows = D.group_rows(n_tok, world, group=4)
+        assert rows == [16, 14] and sum(rows) == n_tok
+        lo = sum(rows[:rank])
+        qa, ka, va = qf, kf, vf                                                  # [b, a2, n_tok, d] whole sequence
+        gp = D.GroupParallelPipeline(dist.group.WORLD, a2, rows, d, torch.float32, torch.device("cpu"), chunks=[2, 3, 3])
+        seen_kv = []
+
+        def attn_g(q, k, v):
+            seen_kv.append((q.shape[1], q.shape[2], k.shape[2]))
+            return F.scaled_dot_product_attention(q, k, v)
+        for rep in range(2):
+            og = gp.run(qa[:, :, lo:lo + rows[rank]].contiguous(), ka[:, :, lo:lo + rows[rank]].contiguous(),
+                        va[:, :, lo:lo + rows[rank]].contiguous(), [attn_g] * 3)
+            torch.testing.assert_close(og, ref2[:, lo:lo + rows[rank]].reshape(b, rows[rank], a2 * d), rtol=1e-5, atol=1e-5)
+        assert seen_kv[:3] == [(2, rows[rank], n_tok), (3, rows[rank], n_tok), (3, rows[rank], n_tok)]
+        assert gp.bytes_per_layer_received == (world - 1) * 2 * b * a2 * max(rows) * d * 4
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -130,3 +160,45 @@ def test_pipeline_without_group_and_chunk_counter(fresh_config):
     assert [v.increment() for v in views] == [(0, 0, 0)] * 3
     assert counter.get_cur_coord() == (0, 1, 0) and views[0].cur_layer == 1
     assert views[1].should_do_full_attn_step() == counter.should_do_full_attn_step()
+
+
+def test_chunk_planner_prefers_overlap_only_when_it_pays():
+    from chipmunk_amd import distributed as D
+    t_attn = lambda h: 0.2 + 0.7 * h          # a launch has a fixed cost: 3 one-head launches cost more than one 3-head launch
+    # free exchange: one launch is best
+    assert D.plan_chunks(3, t_attn, 0.0, 0.0) == [3]
+    # expensive exchange: the pipeline wins, and the simulated makespan of the plan is no worse than any uniform split
+    plan = D.plan_chunks(6, t_attn, 0.5, 0.17)
+    assert sum(plan) == 6 and len(plan) > 1
+    best = D.simulate_chunks(plan, t_attn, 0.5, 0.17)
+    for ch in (1, 2, 3, 6):
+        assert best <= D.simulate_chunks([ch] * (6 // ch), t_attn, 0.5, 0.17) + 1e-12
+    # the simulator itself: one chunk = in + attention + out, fully serial
+    assert abs(D.simulate_chunks([3], t_attn, 0.5, 0.1) - (1.5 + 2.3 + 0.3)) < 1e-12
+    # two chunks: in(0) | in(1) overlaps attn(0) | out(0) overlaps attn(1) | out(1) exposed
+    t = D.simulate_chunks([1, 1], lambda h: 1.0, 0.4, 0.1)
+    assert abs(t - (0.4 + 1.0 + 1.0 + 0.1)) < 1e-12
+    assert D.group_rows(119056, 8) == [14976] * 7 + [14224]
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no rank environment must start 2 ranks itself (the driver's command form);
+    --launch-only makes them rendezvous, all-reduce and report without touching a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-only"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 1
+    assert sorted(r["rank"] for r in line["ranks"]) == [0, 1] and len({r["pid"] for r in line["ranks"]}) == 2
+    # a mismatch between --gpus and the launcher's world is an error, not a silent 1-rank run
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-only"], env=env2,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 4" in (bad.stderr + bad.stdout)

@@ -89,3 +89,36 @@ def test_keep_resident_if_fits_policy(cfg):
     assert big.cpu_buf[0] is not None and big.cpu_buf[0].is_pinned()
     big.load_async(); big.load_async_wait()
     assert torch.equal(big.get_loaded_value(), b)
+
+
+def test_chunk_modules_of_one_layer_have_their_own_load_slots(cfg):
+    """a sequence-parallel rank builds several SparseDiffAttn modules with the SAME layer number (head
+    chunks, distributed.chunk_counters).  With the caches on the host each chunk's load must land in its own device slot;
+    with one shared slot every chunk read the LAST chunk's cache."""
+    from chipmunk_amd.util.storage import AttnStorage
+    from chipmunk_amd.util.storage import offloaded_tensor as ot
+    cfg["offloading"]["global_disable_offloading"] = False
+    cfg["offloading"]["attn.out_cache"] = True
+    cfg["offloading"]["keep_resident_if_fits"] = False
+    dev = torch.device("cuda:0")
+    n_layers, n_chunks = 3, 3
+    store = [[AttnStorage(l, init_names=["out_cache"], slot=c) for c in range(n_chunks)] for l in range(n_layers)]
+    data = [[torch.randn(1, 1 + c, 192, 128, device=dev).to(torch.bfloat16) for c in range(n_chunks)] for _ in range(n_layers)]
+    for l in range(n_layers):
+        for c in range(n_chunks):
+            store[l][c].set_out_cache(data[l][c].clone())
+            assert not store[l][c].out_cache.is_resident()
+    # the bench's loop: wait for this layer's chunks, prefetch the next layer's, then every chunk reads its cache
+    for c in range(n_chunks):
+        store[0][c].load_async()
+    for l in range(n_layers):
+        for c in range(n_chunks):
+            store[l][c].load_async_wait()
+        for c in range(n_chunks):
+            store[(l + 1) % n_layers][c].load_async()
+        got = [store[l][c].get_out_cache() for c in range(n_chunks)]
+        torch.cuda.synchronize()
+        for c in range(n_chunks):
+            assert got[c].shape == data[l][c].shape and torch.equal(got[c], data[l][c]), (l, c)
+        assert len({g.data_ptr() for g in got}) == n_chunks
+    assert set(ot.gpu_tensors) == {"attn.out_cache", "attn.out_cache#1", "attn.out_cache#2"}
