@@ -758,7 +758,8 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // plan, same scratch): HunyuanVideo 24 heads +2 %, a head-parallel rank's 3 heads +6 %; short items (FLUX: 21 tiles) and
     // single heads stay here (its per-item prologue and epilogue are longer).  Option attn_csp96: 1 = always, 2 = never.
     const int o96 = chipmunk_get_option("attn_csp96");
-    const bool fits96 = GATHER && !CSONLY && !WRITE_L && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
+    const bool fits96 = GATHER && !CSONLY && !WRITE_L && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24) &&
+                        (p.idx_stride & 3) == 0;   // (its index rows are read 16 bytes at a time)
     const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 6 * (int64_t)device_cu_count() && p.Nk >= 32768));
     const int o64 = chipmunk_get_option("attn_csp64");
     const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);

@@ -105,11 +105,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int qrow = row0 + qb * 32 + l31;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
+            // Q is folded with log2(e)/sqrt(D) HERE, once per item (bf16(q c), round to nearest even): the MFMA then delivers the
+            // exponent of 2 itself and the loop has no `x = s c - m c` multiply-add per score (48 of 200 VALU issues per tile).
+            // csp_attn / csp_128_attn export no `l`; the bf16 `o` tolerance covers the extra rounding of q.
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
-                qss[qb] = __builtin_fmaf(lo, lo, qss[qb]);
-                qss[qb] = __builtin_fmaf(hi, hi, qss[qb]);
+                const float lo = __uint_as_float(val[e] << 16) * SCALE_LOG2E, hi = __uint_as_float(val[e] & 0xffff0000u) * SCALE_LOG2E;
+                val[e] = pack_bf16x2(lo, hi);
+                const float rlo = __uint_as_float(val[e] << 16), rhi = __uint_as_float(val[e] & 0xffff0000u);
+                qss[qb] = __builtin_fmaf(rlo, rlo, qss[qb]);
+                qss[qb] = __builtin_fmaf(rhi, rhi, qss[qb]);
             }
             if constexpr (qb == 0) qv[ks] = val;
             else if constexpr (qb == 2) acc_write4<224 + ks * 4>(val);
@@ -134,23 +139,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) kswz[i] = (uint32_t)(l15 ^ (4 * i + lg)) << 4;
     const uint32_t vswz = (uint32_t)(l15 ^ (lg << 2)) << 4;
-    const bool idx_vec = ((uintptr_t)idx & 15) == 0 && (p.idx_stride & 3) == 0;
-    auto load_idx = [&](int T) {
-        const int base = (tbeg + T) * KT + w * 16 + lg * 4;
-        u32x4 v4;
-        if (idx_vec && (tbeg + T) * KT + KT <= p.idx_stride) {
-            v4 = *(const u32x4 *)(idx + base);
-        } else {
+    // index rows through a buffer resource sized to the row: no 64-bit lane addresses, and positions past the row's end read 0
+    // (hardware range check) -- padding tiles are masked, key 0 is as good as any
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, p.idx_stride * 4, 0x00020000);
+    const int nk1 = p.Nk - 1;
+    auto load_idx = [&](int T) {   // (idx_stride is a multiple of 4 here: launch_attn sends other launches to the general kernel)
+        const int base = ((tbeg + T) * KT + w * 16 + lg * 4) * 4;
+        u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(irsrc, base, 0, 0);
+        return v4;   // raw: clamped at first use, an iteration later (a clamp here would wait for the load and every DMA in flight)
+    };
+    auto clamp_idx = [&](u32x4 &v4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int pos = base + e;
-                pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
-                v4[e] = (uint32_t)idx[pos];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = (uint32_t)max(0, min((int)v4[e], p.Nk - 1));   // memory safety for malformed indices
-        return v4;
+        for (int e = 0; e < 4; ++e)   // memory safety for malformed indices: clamp to [0, Nk-1] (one v_med3 each)
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(v4[e]) : "v"(v4[e]), "v"(nk1));
     };
     auto issue_k1 = [&](const u32x4 &keys, int slot, int i) {
         blds16(krsrc, __umul24(keys[i], kstride_b) + kswz[i], 0, smem + slot * TB + (4 * w + i) * 1024);
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //      its slot so that the first tile's PV -- P = 0 -- multiplies finite numbers)
     u32x4 ir[4];   // gather keys of four tiles (entry = tile mod 4)
     ir[0] = load_idx(0), ir[1] = load_idx(1), ir[2] = load_idx(2), ir[3] = load_idx(3);
+    clamp_idx(ir[0]), clamp_idx(ir[1]), clamp_idx(ir[2]), clamp_idx(ir[3]);
     issue_k(ir[0], 0);
     issue_k(ir[1], 1), issue_v(ir[0], 3);
     issue_k(ir[2], 2), issue_v(ir[0], 0);
@@ -248,14 +250,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto update_block = [&](auto qq, float mx) __attribute__((always_inline)) {
         constexpr int QB = decltype(qq)::value;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > mlag[QB]) != 0, 0)) {
-            constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
-            const float m_new = max2(m[QB], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m[QB] - m_new) * SCALE_LOG2E);
+            const float m_new = max2(m[QB], mx);          // (scores arrive in exponent units: Q carries log2(e)/sqrt(D))
+            const float alpha = __builtin_amdgcn_exp2f(m[QB] - m_new);
             lacc[QB][0] *= alpha;
             lacc[QB][1] *= alpha;
             m[QB] = m_new;
-            nmsc[QB] = -m_new * SCALE_LOG2E;
-            mlag[QB] = m_new + LAG_RAW;
+            nmsc[QB] = -m_new;
+            mlag[QB] = m_new + MAX_LAG;
             float tmp;
             if constexpr (QB == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB0 : "=&v"(tmp) : "v"(alpha));
             if constexpr (QB == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB1 : "=&v"(tmp) : "v"(alpha));
@@ -263,12 +264,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // window slot W (0..23) of block QB's x / exp2 / row sum / pack pipeline, in place on its score registers
-    auto window = [&](auto qq, auto wc) __attribute__((always_inline)) {
+    auto window = [&](auto qq, auto wc, auto nmc) __attribute__((always_inline)) {
         constexpr int QB = decltype(qq)::value, W = decltype(wc)::value;
-        if constexpr (W < 4) {
+        constexpr bool NOMAX = decltype(nmc)::value != 0;
+        if constexpr (W < 4 && !NOMAX) {   // x = s - m (running-maximum form only: the fixed form takes exp2 of the score itself)
             static_for<4 * W, 4 * W + 4>([&](auto ee) {
                 constexpr int E = decltype(ee)::value;
-                float x = __builtin_fmaf(s[QB][E], SCALE_LOG2E, nmsc[QB]);
+                float x = s[QB][E] + nmsc[QB];
                 pin(x);
                 s[QB][E] = x;
             });
@@ -299,8 +301,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago; an iteration is 8 pieces + 1 (4) index loads
         if constexpr (!(A96_ABL & 4)) {
-            if (idx_vec) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         P96_MARK(0);
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 if constexpr (SG % 4 == 2 && SG < 32 && !(A96_ABL & 4)) {   // the DMA of K(t+4) -> slot of K(t), V(t+2) -> slot of V(t-2)
                     constexpr int PC = (SG - 2) / 4;
+                    if constexpr (PC == 0) clamp_idx(ir[SL]);   // loaded an iteration ago; V(t+4) reuses the clamped keys two iterations on
                     if constexpr (PC < 4) issue_k1(ir[SL], SL, PC);
                     else issue_v1(ir[(SL + 2) & 3], (SL + 2) & 3, PC - 4);
                 }
@@ -349,18 +351,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (SG >= 1 && SG <= 4 && !NOMAX) max_step(ic<SG - 1>{}, s[2], mxc);
             if constexpr (SG == 5 && !NOMAX) max_halves(mxc);
             if constexpr (SG == 7 && !NOMAX) update_block(ic<2>{}, mxc);
-            if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{});
-            if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{});                  // block 1 of tile t-1, second part
+            if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{}, nmc);
+            if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{}, nmc);                  // block 1 of tile t-1, second part
             if constexpr (SG == 16) mask_block(s[0], vl_cur);                       // block 0 of tile t
             if constexpr (SG >= 17 && SG <= 20 && !NOMAX) max_step(ic<SG - 17>{}, s[0], mxa);
             if constexpr (SG == 21 && !NOMAX) max_halves(mxa);
             if constexpr (SG == 23 && !NOMAX) update_block(ic<0>{}, mxa);
-            if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{});
+            if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{}, nmc);
             if constexpr (SG == 32) mask_block(s[1], vl_cur);                       // block 1 of tile t
             if constexpr (SG >= 33 && SG <= 36 && !NOMAX) max_step(ic<SG - 33>{}, s[1], mxb);
             if constexpr (SG == 37 && !NOMAX) max_halves(mxb);
             if constexpr (SG == 39 && !NOMAX) update_block(ic<1>{}, mxb);
-            if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{});
+            if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{}, nmc);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -370,9 +372,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // tiles 0 .. T4-1 (padding tiles are fully masked), one more tile's worth of slots for the pipelines in flight, then the
     // last three PV elements of block 2
-    // Fixed reference point (as in attn64.hip): |s_ij| <= |q_i| max_j |k_j| =: M_i over ALL keys of the head, a fortiori over the
-    // gathered ones; if 2 M c <= 64 for every query of the wave, p = exp2((s - M) c) stays inside the normal range and the
-    // maxima / update / rescale work (48 of ~400 issues per tile) is not needed.  Per wave; changes nothing but rounding.
+    // No reference point at all where that is provably safe: |s_ij| <= |q_i| max_j |k_j| =: M_i (exponent units, q already carries
+    // log2(e)/sqrt(D)) over ALL keys of the head, a fortiori over the gathered ones.  If M_i <= 56 for every query of the wave,
+    // p = exp2(s) lies in [2^-56, 2^56]: normal numbers in fp32 and in the bf16 P, row sums and O below 2^56 * 2^17 * max|v| --
+    // nothing overflows, nothing is flushed, and floating point is scale invariant (o = O / l).  Then neither the maxima /
+    // update / rescale work nor the subtraction exists in the loop.  Per wave; changes nothing but rounding.
     bool nomax = false;
     if (p.kmax) {
         const float km = p.kmax[bh];
@@ -382,12 +386,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float a = qss[qb], c2 = qss[qb];
             lane_swap32(a, c2);
             qss[qb] = __builtin_sqrtf(a + c2) * km;
-            ok = ok && (2.0f * qss[qb] * SCALE_LOG2E <= 64.0f);
+            ok = ok && (qss[qb] <= 56.0f);
         }
         nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
         if (nomax) {
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) m[qb] = qss[qb], nmsc[qb] = -qss[qb] * SCALE_LOG2E, mlag[qb] = INFINITY;
+            for (int qb = 0; qb < 3; ++qb) m[qb] = 0.f, nmsc[qb] = 0.f, mlag[qb] = INFINITY;
         }
     }
     if (nomax) {
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float ms = oth[(192 + qb) * 128], ls = oth[(195 + qb) * 128];
             const float m_new = fmaxf(mm, ms);
             if (m_new == -INFINITY) continue;  // nothing so far and an empty slice
-            const float a = __builtin_amdgcn_exp2f((mm - m_new) * SCALE_LOG2E);
-            const float c = __builtin_amdgcn_exp2f((ms - m_new) * SCALE_LOG2E);
+            const float a = __builtin_amdgcn_exp2f(mm - m_new);   // (m in exponent units)
+            const float c = __builtin_amdgcn_exp2f(ms - m_new);
             mm = m_new;
             ll = ll * a + ls * c;
 #pragma unroll

@@ -101,7 +101,7 @@ def test_chunk_modules_of_one_layer_have_their_own_load_slots(cfg):
     cfg["offloading"]["attn.out_cache"] = True
     cfg["offloading"]["keep_resident_if_fits"] = False
     dev = torch.device("cuda:0")
-    n_layers, n_chunks = 3, 3
+    n_layers, n_chunks = 4, 3
     store = [[AttnStorage(l, init_names=["out_cache"], slot=c) for c in range(n_chunks)] for l in range(n_layers)]
     data = [[torch.randn(1, 1 + c, 192, 128, device=dev).to(torch.bfloat16) for c in range(n_chunks)] for _ in range(n_layers)]
     for l in range(n_layers):
