@@ -8,9 +8,10 @@
 //     file) -- accumulator registers are only ever named from inline asm (same audit rule as attn64.hip);
 //   * swapped layout S^T = K.Q^T on v_mfma_f32_32x32x16_bf16: a lane owns a query column, softmax statistics are
 //     lane-local, the bf16 P^T feeds O^T += V^T.P^T from registers;
-//   * per 32-key tile ONE stream of 48 MFMAs, QK^T and PV alternating, query block by query block; the softmax of a
-//     block runs IN PLACE on its score registers as a 31-slot pipeline while the other blocks' MFMAs issue, the three
-//     pipelines staggered by 16 slots (see the main loop's comment);
+//   * per 32-key tile ONE stream of 48 MFMAs, QK^T and PV alternating; the softmax of a block runs IN PLACE on its score
+//     registers as a pipeline while the other blocks' MFMAs issue, the three pipelines staggered by 16 slots; the PV
+//     stream handles query blocks 0 and 1 in PAIRS that share one V^T fragment read (see the main loop's comment; the
+//     slot tables and lgkmcnt values come from tools/gen_attn96_sched.py, which asserts every ordering constraint);
 //   * gather: each wave stages half of every K and V tile by LDS-DMA (4 + 4 pieces); LDS row 4*pc + lg of a tile holds
 //     packed position (pc >> 2)*16 + lg*4 + (pc & 3), so a lane group reads 4 consecutive indices per tile and piece i
 //     takes register i; index registers of four tiles in a ring; one s_barrier (two waves) + one counted vmcnt per tile;
@@ -19,6 +20,7 @@
 #include "attn64_regs.h"
 #include "attn_params.h"
 #include "attn64_util.h"
+#include "attn96_sched.h"
 
 namespace {
 
@@ -187,16 +189,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   even sigma: S(t)[qb] += K(t)[ks] . Q^T[qb][ks], qb = sigma/16, ks = (sigma%16)/2 -- query block by query block, so
     //               block qb's scores are complete at sigma = 16 qb + 14 and its softmax can start while the other blocks'
     //               MFMAs are still running (a dependent chain on one accumulator, but every other MFMA is a PV one);
-    //   odd sigma = 2i+1: the PV element that is three V^T fragment reads old: O[qb'] += V^T . P^T, elements in
-    //               query-block-major order j = qb'*8 + slab*4 + db, stream shifted by three: i < 3 runs tile t-2's j = 21 + i,
-    //               i >= 3 tile t-1's j = i - 3; then the read of fragment i of V(t-1) into the 4-deep window.
-    // The softmax of a block is a 31-slot pipeline (maxima, [rare] reference update + rescale of that block's 64
-    // accumulator registers, then x / exp2 / row sum / bf16 pair, one instruction per stage and slot); the three blocks'
-    // pipelines are staggered by 16 slots, block 1 runs over the tile seam and block 2 entirely in the next tile, so the
-    // VALU load is ~5 issues per slot everywhere and every P^T fragment is complete before the first PV MFMA that reads it
-    // and written only after the last one that read its predecessor.  K(t+1) fragment ks is re-read right after block 2's
-    // MFMA on k step ks; the Q^T block-1 window is 4 k steps deep.  All LDS reads are asm, waited for by count inside
-    // the consuming MFMA's statement (reads return in order; the counts are lower bounds of the younger reads in flight).
+    //   odd sigma = 2i+1: PV element i, O[qb'] += V^T fragment . P^T, from the slot tables of attn96_sched.h:
+    //               * loop without a reference point (Pair): i < 3 the last three elements of block 2 of tile t-2, i = 3..18 query
+    //                 blocks 0 and 1 of tile t-1 in PAIRS on one V^T fragment (16 fragment reads per tile instead of 24; P[0] is
+    //                 double-buffered by tile parity because its reads now overlap the next tile's packs), i >= 19 block 2 of t-1;
+    //               * running-maximum loop (Major): query-block-major, so that every element of a block precedes the slot in
+    //                 which that block's reference point may move (the rescale of its 64 accumulator registers).
+    // The softmax of a block is a pipeline (maxima, [rare] reference update + rescale, then exp2 / row sum / bf16 pair, one
+    // instruction per stage and slot; the running-maximum form also x = s - m); the three blocks' pipelines are staggered by
+    // 16 slots, block 1 runs over the tile seam and block 2 entirely in the next tile.  LDS reads -- two 8-byte halves per V^T
+    // fragment into a 4-entry window, the Q^T block-1 window (4 k steps deep), K(t+1) fragment ks after block 2's MFMA on k
+    // step ks -- are spread one or two per slot over ALL slots (2-3 after every PV MFMA and none after the QK^T ones made the
+    // odd slots 6-8 issues long and left the even ones at 3: a slot cannot be shorter than its MFMA).  The generator asserts
+    // that every P^T fragment is complete before the first PV MFMA that reads it and written only after the last one that read
+    // its predecessor, the same for the windows, and computes the lgkmcnt in front of each consumer (reads return in order).
     f32x16 s[3];
 #pragma unroll
     for (int q2 = 0; q2 < 3; ++q2)
@@ -204,19 +210,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) s[q2][r] = -INFINITY;   // "tile -1": exp2 -> p = 0
 #pragma unroll
     for (int r = 0; r < 7; ++r) s[1][r] = 0.f;   // (block 1's first seven elements are past the exp2 stage at the tile seam: p = 0)
-    u32x4 pw[3][2] = {};         // P^T fragments (block, key slab)
-    u32x4 vfw[4] = {};           // V^T fragment window (zero: the first PV elements multiply P = 0 by it)
+    u32x4 pw[3][2] = {};         // P^T fragments (block, key slab); block 0 of EVEN tiles (its reads for tile t-1 overlap its
+    u32x4 pwo[2] = {};           //   packs for tile t: double-buffered by tile parity -- block 0 of ODD tiles lives here)
+    u32x2 vlo[4] = {}, vhi[4] = {};   // V^T fragment window, two 8-byte halves per entry (zero: the first PV elements multiply P = 0 by it)
     u32x4 q1w[4] = {};           // Q^T block-1 window
     float m[3] = {-INFINITY, -INFINITY, -INFINITY}, nmsc[3] = {0.f, 0.f, 0.f}, mlag[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lacc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     int vl_prev = KT;            // packed positions that exist in the previous tile (its block 2 is masked in this one)
 
-    auto vfrag_read = [&](auto dbc, auto offc, u32x4 &dst) __attribute__((always_inline)) {
-        constexpr int DB = decltype(dbc)::value, OFF = decltype(offc)::value;
-        u32x2 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
-                     : "=v"(lo), "=v"(hi) : "v"(vad[DB]), "i"(OFF), "i"(OFF + 2048) : "memory");
-        dst = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    auto vhalf_read = [](uint32_t addr, auto offc, u32x2 &dst) __attribute__((always_inline)) {
+        constexpr int OFF = decltype(offc)::value;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
     };
     auto q1_read = [&](auto ksc, u32x4 &dst) __attribute__((always_inline)) {
         constexpr int KS = decltype(ksc)::value;
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // window slot W (0..23) of block QB's x / exp2 / row sum / pack pipeline, in place on its score registers
-    auto window = [&](auto qq, auto wc, auto nmc) __attribute__((always_inline)) {
-        constexpr int QB = decltype(qq)::value, W = decltype(wc)::value;
+    auto window = [&](auto qq, auto wc, auto nmc, auto parc) __attribute__((always_inline)) {
+        constexpr int QB = decltype(qq)::value, W = decltype(wc)::value, PAR = decltype(parc)::value;   // PAR: parity of the block's tile
         constexpr bool NOMAX = decltype(nmc)::value != 0;
         if constexpr (W < 4 && !NOMAX) {   // x = s - m (running-maximum form only: the fixed form takes exp2 of the score itself)
             static_for<4 * W, 4 * W + 4>([&](auto ee) {
@@ -284,11 +288,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lacc[QB][W & 1] += s[QB][W - 2];
             pin(lacc[QB][W & 1]);
         }
-        if constexpr (W >= 5 && W <= 19 && (W & 1) == 1) {
-            constexpr int K = (W - 5) >> 1;   // pair (2K, 2K+1): slab K >> 2, dword K & 3
+        if constexpr (W >= 6 && W <= 20 && (W & 1) == 0) {   // (even W = even slots: the odd ones carry the LDS reads)
+            constexpr int K = (W - 6) >> 1;   // pair (2K, 2K+1): slab K >> 2, dword K & 3
             uint32_t pk = pack_bf16x2(s[QB][2 * K], s[QB][2 * K + 1]);
             pin(pk);
-            pw[QB][K >> 2][K & 3] = pk;
+            if constexpr (QB == 0 && PAR == 1) pwo[K >> 2][K & 3] = pk;
+            else pw[QB][K >> 2][K & 3] = pk;
         }
     };
 
@@ -309,20 +314,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int vl_cur = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist
         float mxa, mxb, mxc;   // block maxima: this tile's block 0, this tile's block 1, the previous tile's block 2
         __builtin_amdgcn_sched_barrier(0);
+        using S = std::conditional_t<NOMAX, a96s::Pair, a96s::Major>;   // slot tables (tools/gen_attn96_sched.py)
         static_for<0, 48>([&](auto sg) {
             constexpr int SG = decltype(sg)::value;
+            // LDS reads return in order: a wait states how many of the youngest may still be in flight
+            if constexpr (S::WAIT[SG] >= 0 && !(A96_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(S::WAIT[SG]) : "memory");
             if constexpr ((SG & 1) == 0) {   // ---- QK^T
                 constexpr int qb = SG / 16, ks = (SG % 16) / 2, ka = 192 + ks * 4, qa = 224 + ks * 4;
                 if constexpr (qb == 2) {
                     if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
                     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s[2]) : "i"(ka), "i"(ka + 3), "i"(qa), "i"(qa + 3));
                 } else {
-                    // LDS reads return in order: a wait states how many of the youngest may still be in flight.  Block 0 waits
-                    // twice for its K fragments (re-read at slots 33..47 of the previous tile), block 1 four times for its window
-                    // (fragment ks read at slot 9 + 2 ks); the counts are the reads issued since, slot by slot.
-                    constexpr int WAIT = qb == 0 ? (ks == 0 ? 12 : ks == 4 ? 8 : -1) : (ks == 6 ? 4 : (ks & 1) == 0 ? 6 : -1);
                     const u32x4 &qf = qb == 0 ? qv[ks] : q1w[ks & 3];
-                    if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(WAIT) : "memory");
                     if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, 0" : "=v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
                     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(s[qb]) : "i"(ka), "i"(ka + 3), "v"(qf));
                 }
@@ -332,37 +335,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if constexpr (PC < 4) issue_k1(ir[SL], SL, PC);
                     else issue_v1(ir[(SL + 2) & 3], (SL + 2) & 3, PC - 4);
                 }
-            } else {                         // ---- PV
-                constexpr int I = (SG - 1) / 2, J = (I + 21) % 24, qbp = J / 8, up = (J % 8) / 4, db = J % 4, oa = (qbp * 4 + db) * 16;
-                // every other element waits, for its own fragment and the next one's: all but the previous slot's reads (two for the
-                // V^T fragment, one more where that slot also re-read a K fragment or a window fragment) have landed
-                if constexpr ((I & 1) == 0) {
-                    constexpr int PS = SG - 2, EXTRA = ((PS >= 9 && PS <= 23) || PS >= 33 || PS < 0) ? 1 : 0;   // (PS < 0: slot 47 of the tile before)
-                    asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(2 + EXTRA) : "memory");
-                }
-                asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vfw[J & 3]), "v"(pw[qbp][up]), "i"(oa), "i"(oa + 15));
-                if constexpr (!(A96_ABL & 2)) vfrag_read(ic<(I % 4)>{}, ic<VSL * TB + ((I % 8) / 4) * 4096>{}, vfw[I & 3]);   // fragment I of V(t-1): d block I%4, slab (I%8)/4
-                if constexpr (SG >= 9 && SG <= 23 && !(A96_ABL & 8)) q1_read(ic<(SG - 9) / 2>{}, q1w[((SG - 9) / 2) & 3]);
-                if constexpr (SG >= 33 && !(A96_ABL & 8)) lds_k<(SG - 33) / 2, KNSL>(kad[(SG - 33) / 2]);
+            } else {                         // ---- PV: O^T[qb][db] += V^T fragment (slab, db) . P^T[qb][slab]
+                constexpr int I = (SG - 1) / 2, qbp = S::PV_QB[I], f = S::PV_F[I], e = S::PV_U[I], oa = (qbp * 4 + (f & 3)) * 16;
+                const u32x4 vf = {vlo[e][0], vlo[e][1], vhi[e][0], vhi[e][1]};
+                // block 0's P^T of tile t-1 (elements 0..2 belong to block 2): the buffer of that tile's parity
+                const u32x4 &pf = (qbp == 0 && ((SL + 1) & 1) == 1) ? pwo[f >> 2] : pw[qbp][f >> 2];
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(oa), "i"(oa + 15));
             }
+            // ---- the slot's LDS reads: halves of V^T fragments of V(t-1), the Q^T block-1 window, K(t+1) fragments
+            static_for<0, 2>([&](auto jj) {
+                constexpr int J = decltype(jj)::value;
+                constexpr int kind = J == 0 ? S::RD_KIND0[SG] : S::RD_KIND1[SG], arg = J == 0 ? S::RD_ARG0[SG] : S::RD_ARG1[SG];
+                if constexpr ((kind == 1 || kind == 2) && !(A96_ABL & 2)) {
+                    constexpr int en = arg >> 3, fr = arg & 7, off = VSL * TB + (fr >> 2) * 4096 + (kind == 2 ? 2048 : 0);
+                    vhalf_read(vad[fr & 3], ic<off>{}, kind == 1 ? vlo[en] : vhi[en]);
+                }
+                if constexpr (kind == 3 && !(A96_ABL & 8)) q1_read(ic<arg>{}, q1w[arg & 3]);
+                if constexpr (kind == 4 && !(A96_ABL & 8)) lds_k<arg, KNSL>(kad[arg]);
+            });
             // ---- the three softmax pipelines
             if constexpr (!(A96_ABL & 1)) {
             if constexpr (SG == 0) mask_block(s[2], vl_prev);                       // block 2 of tile t-1
             if constexpr (SG >= 1 && SG <= 4 && !NOMAX) max_step(ic<SG - 1>{}, s[2], mxc);
             if constexpr (SG == 5 && !NOMAX) max_halves(mxc);
             if constexpr (SG == 7 && !NOMAX) update_block(ic<2>{}, mxc);
-            if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{}, nmc);
-            if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{}, nmc);                  // block 1 of tile t-1, second part
+            if constexpr (SG >= 8 && SG <= 31) window(ic<2>{}, ic<SG - 8>{}, nmc, ic<0>{});
+            if constexpr (SG <= 15) window(ic<1>{}, ic<SG + 8>{}, nmc, ic<0>{});                  // block 1 of tile t-1, second part
             if constexpr (SG == 16) mask_block(s[0], vl_cur);                       // block 0 of tile t
             if constexpr (SG >= 17 && SG <= 20 && !NOMAX) max_step(ic<SG - 17>{}, s[0], mxa);
             if constexpr (SG == 21 && !NOMAX) max_halves(mxa);
             if constexpr (SG == 23 && !NOMAX) update_block(ic<0>{}, mxa);
-            if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{}, nmc);
+            if constexpr (SG >= 24) window(ic<0>{}, ic<SG - 24>{}, nmc, ic<(SL & 1)>{});
             if constexpr (SG == 32) mask_block(s[1], vl_cur);                       // block 1 of tile t
             if constexpr (SG >= 33 && SG <= 36 && !NOMAX) max_step(ic<SG - 33>{}, s[1], mxb);
             if constexpr (SG == 37 && !NOMAX) max_halves(mxb);
             if constexpr (SG == 39 && !NOMAX) update_block(ic<1>{}, mxb);
-            if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{}, nmc);
+            if constexpr (SG >= 40) window(ic<1>{}, ic<SG - 40>{}, nmc, ic<0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -411,10 +419,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             tile(ic<3>{}, ic<0>{}, tb + 3);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfw[1]), "+v"(vfw[2]), "+v"(vfw[3]));
-    mfma_pv<2, 1>(vfw[1], pw[2][1]);
-    mfma_pv<2, 2>(vfw[2], pw[2][1]);
-    mfma_pv<2, 3>(vfw[3], pw[2][1]);
+    // (the last three elements of block 2 of the last real tile: fragments f = 5, 6, 7, read into entries 0..2 by the last iteration)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]), "+v"(vlo[2]), "+v"(vhi[2]));
+    mfma_pv<2, 1>((u32x4){vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]}, pw[2][1]);
+    mfma_pv<2, 2>((u32x4){vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]}, pw[2][1]);
+    mfma_pv<2, 3>((u32x4){vlo[2][0], vlo[2][1], vhi[2][0], vhi[2][1]}, pw[2][1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P96_END(w, T4 + 1);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");

@@ -118,6 +118,34 @@ def test_csp64_random_indices_vs_oracle(dev, forced_csp, n, nk, count):
     assert_close_bf16(o, o_ref, what=f"csp64 {n}x{nk} count {count}")
 
 
+@pytest.mark.parametrize("how", ["option", "large_scores"])
+def test_csp96_running_maximum_schedule_vs_oracle(dev, how):
+    """attn96.hip has two slot schedules (tools/gen_attn96_sched.py): the paired PV order of the loop without a reference point
+    and the query-block-major one of the running-maximum loop.  The second one runs when the |q| max|k| bound is too large
+    (here: q, k x 3) or when option attn_nomax = 2 switches the bound off; ragged counts, a masked tail, sliced heavy items."""
+    import math
+    from chipmunk_amd import _native
+    from helpers import random_index_sets
+    H, n = 3, 2304
+    sc = 3.0 if how == "large_scores" else 1.0
+    q, k = [(randn_bf16(1, H, n, 128, seed=s).float() * sc).to(torch.bfloat16) for s in (51, 52)]
+    v = randn_bf16(1, H, n, 128, seed=53)
+    G = math.ceil(n / 192)
+    inds, counts = random_index_sets(1, H, G, n, 640, n, seed=4)
+    counts[0, 0, 1], counts[0, 1, 2], counts[0, 2, 3] = 37, 0, n
+    inds[0, 2, 3] = torch.arange(n, dtype=torch.int32)
+    o_ref = oracle.csp_128_attn(q, k, v, inds, counts)
+    _native.set_option("attn_csp96", 1)
+    _native.set_option("attn_nomax", 2 if how == "option" else 0)
+    try:
+        o = torch.ops.chipmunk.csp_128_attn(q.to(dev), k.to(dev), v.to(dev), inds.to(dev), counts.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        _native.set_option("attn_csp96", 0)
+        _native.set_option("attn_nomax", 0)
+    assert_close_bf16(o, o_ref, what=f"csp96 running-maximum schedule ({how})")
+
+
 @pytest.mark.parametrize("o_scale", [1, -1])
 def test_csp64_inplace_and_out_forms(dev, forced_csp, o_scale):
     import math
