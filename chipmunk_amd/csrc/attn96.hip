@@ -99,29 +99,53 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // block 0 in 32 VGPRs, block 2 in a[224:255], block 1 staged in LDS (its 32 registers do not fit beside the softmax) and
     // streamed through a two-fragment window, one ds_read_b128 per k step and tile
     u32x4 qv[8];
-    float qss[3] = {0.f, 0.f, 0.f};   // this lane's half of |q|^2 per query block (fixed reference point, see the loop selection)
+    // The loop WITHOUT a reference point (see the loop selection below) is possible where |s_ij| <= |q_i| max_j |k_j| =: M_i is
+    // provably small for every query of the wave: |q_i|^2 of the wave's rows -> the decision (wave-uniform).
+    bool nomax = false;
     {
         const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1];
-        static_for<0, 24>([&](auto f) {
-            constexpr int F = decltype(f)::value, qb = F >> 3, ks = F & 7;
-            const int qrow = row0 + qb * 32 + l31;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
-            // Q is folded with log2(e)/sqrt(D) HERE, once per item (bf16(q c), round to nearest even): the MFMA then delivers the
-            // exponent of 2 itself and the loop has no `x = s c - m c` multiply-add per score (48 of 200 VALU issues per tile).
-            // csp_attn / csp_128_attn export no `l`; the bf16 `o` tolerance covers the extra rounding of q.
+        float qss[3] = {0.f, 0.f, 0.f};   // this lane's half of |q|^2 per query block
+        // The Q^T fragments.  For the loop without a reference point Q is folded with log2(e)/sqrt(D) HERE, once per item
+        // (bf16(q c), round to nearest even): the MFMA then delivers the exponent of 2 itself and the loop has no per-score
+        // multiply-add (48 of 200 VALU issues per tile).  The rounding of q c moves an exponent by at most |s| c 2^-9, which the
+        // bound below keeps at <= 0.11 (measured at C3 size: error / tolerance 0.016 at unit scale, 0.13 with q x 2; unbounded it
+        // reached 1.5 at q x 6).  The running-maximum loop keeps the exact q and its multiply-add: the folded fragments are
+        // written optimistically, and a wave that fails the bound fetches its rows again (from L2) and stores them as they are.
+        auto load_q = [&](auto foldc) {
+            constexpr bool FOLD = decltype(foldc)::value != 0;
+            static_for<0, 24>([&](auto f) {
+                constexpr int F = decltype(f)::value, qb = F >> 3, ks = F & 7;
+                const int qrow = row0 + qb * 32 + l31;
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (qrow < p.Nq) val = *(const u32x4 *)(qp + (int64_t)qrow * p.qs[2] + ks * 16 + hf * 8);
+                if constexpr (FOLD) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(val[e] << 16) * SCALE_LOG2E, hi = __uint_as_float(val[e] & 0xffff0000u) * SCALE_LOG2E;
-                val[e] = pack_bf16x2(lo, hi);
-                const float rlo = __uint_as_float(val[e] << 16), rhi = __uint_as_float(val[e] & 0xffff0000u);
-                qss[qb] = __builtin_fmaf(rlo, rlo, qss[qb]);
-                qss[qb] = __builtin_fmaf(rhi, rhi, qss[qb]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
+                        qss[qb] = __builtin_fmaf(lo, lo, qss[qb]);
+                        qss[qb] = __builtin_fmaf(hi, hi, qss[qb]);
+                        val[e] = pack_bf16x2(lo * SCALE_LOG2E, hi * SCALE_LOG2E);
+                    }
+                }
+                if constexpr (qb == 0) qv[ks] = val;
+                else if constexpr (qb == 2) acc_write4<224 + ks * 4>(val);
+                else *(u32x4 *)(smem + QLDS + w * 8192 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4)) = val;   // (own wave's rows only)
+            });
+        };
+        load_q(ic<1>{});
+        if (p.kmax) {
+            const float km = p.kmax[bh];
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                float a = qss[qb], c2 = qss[qb];
+                lane_swap32(a, c2);
+                // M_i in exponent units, with room for the bf16 rounding of the folded Q (|q'| <= |q c| (1 + 2^-8))
+                ok = ok && (__builtin_sqrtf(a + c2) * km * SCALE_LOG2E <= 55.0f);
             }
-            if constexpr (qb == 0) qv[ks] = val;
-            else if constexpr (qb == 2) acc_write4<224 + ks * 4>(val);
-            else *(u32x4 *)(smem + QLDS + w * 8192 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4)) = val;   // (own wave's rows only)
-        });
+            nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        }
+        if (!nomax) load_q(ic<0>{});
     }
 
     // ---- lane-constant LDS addresses (tile = [32 rows][256 B]; K chunk swizzle c ^ (r & 15), V chunk swizzle c ^ ((r & 3) << 2))
@@ -254,13 +278,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto update_block = [&](auto qq, float mx) __attribute__((always_inline)) {
         constexpr int QB = decltype(qq)::value;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > mlag[QB]) != 0, 0)) {
-            const float m_new = max2(m[QB], mx);          // (scores arrive in exponent units: Q carries log2(e)/sqrt(D))
+            constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;
+            const float m_new = max2(m[QB], mx * SCALE_LOG2E);   // m in exponent units (the merge of key slices compares them), mx raw
             const float alpha = __builtin_amdgcn_exp2f(m[QB] - m_new);
             lacc[QB][0] *= alpha;
             lacc[QB][1] *= alpha;
             m[QB] = m_new;
             nmsc[QB] = -m_new;
-            mlag[QB] = m_new + MAX_LAG;
+            mlag[QB] = m_new * (1.0f / SCALE_LOG2E) + LAG_RAW;   // raw units: compared with the raw block maximum
             float tmp;
             if constexpr (QB == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB0 : "=&v"(tmp) : "v"(alpha));
             if constexpr (QB == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" A96_SCALE_QB1 : "=&v"(tmp) : "v"(alpha));
@@ -271,10 +296,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto window = [&](auto qq, auto wc, auto nmc, auto parc) __attribute__((always_inline)) {
         constexpr int QB = decltype(qq)::value, W = decltype(wc)::value, PAR = decltype(parc)::value;   // PAR: parity of the block's tile
         constexpr bool NOMAX = decltype(nmc)::value != 0;
-        if constexpr (W < 4 && !NOMAX) {   // x = s - m (running-maximum form only: the fixed form takes exp2 of the score itself)
+        if constexpr (W < 4 && !NOMAX) {   // x = s c - m (running-maximum form only: the other takes exp2 of the score itself)
             static_for<4 * W, 4 * W + 4>([&](auto ee) {
                 constexpr int E = decltype(ee)::value;
-                float x = s[QB][E] + nmsc[QB];
+                float x = __builtin_fmaf(s[QB][E], SCALE_LOG2E, nmsc[QB]);
                 pin(x);
                 s[QB][E] = x;
             });
@@ -380,27 +405,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // tiles 0 .. T4-1 (padding tiles are fully masked), one more tile's worth of slots for the pipelines in flight, then the
     // last three PV elements of block 2
-    // No reference point at all where that is provably safe: |s_ij| <= |q_i| max_j |k_j| =: M_i (exponent units, q already carries
-    // log2(e)/sqrt(D)) over ALL keys of the head, a fortiori over the gathered ones.  If M_i <= 56 for every query of the wave,
-    // p = exp2(s) lies in [2^-56, 2^56]: normal numbers in fp32 and in the bf16 P, row sums and O below 2^56 * 2^17 * max|v| --
-    // nothing overflows, nothing is flushed, and floating point is scale invariant (o = O / l).  Then neither the maxima /
-    // update / rescale work nor the subtraction exists in the loop.  Per wave; changes nothing but rounding.
-    bool nomax = false;
-    if (p.kmax) {
-        const float km = p.kmax[bh];
-        bool ok = true;
+    // No reference point at all where that is provably safe (decided in the prologue): |s_ij| <= M_i <= 55 exponent units over ALL
+    // keys of the head, a fortiori over the gathered ones, so p = exp2(s) lies in [2^-56, 2^56]: normal numbers in fp32 and in the
+    // bf16 P, row sums and O below 2^56 * 2^17 * max|v| -- nothing overflows, nothing is flushed, and floating point is scale
+    // invariant (o = O / l).  Then neither the maxima / update / rescale work nor the subtraction exists in the loop.  Per wave;
+    // changes nothing but rounding.  (m = 0 for the merge of key slices: every slice of an item takes the same path.)
+    if (nomax) {
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
-            float a = qss[qb], c2 = qss[qb];
-            lane_swap32(a, c2);
-            qss[qb] = __builtin_sqrtf(a + c2) * km;
-            ok = ok && (qss[qb] <= 56.0f);
-        }
-        nomax = __builtin_amdgcn_ballot_w64(!ok) == 0;
-        if (nomax) {
-#pragma unroll
-            for (int qb = 0; qb < 3; ++qb) m[qb] = 0.f, nmsc[qb] = 0.f, mlag[qb] = INFINITY;
-        }
+        for (int qb = 0; qb < 3; ++qb) m[qb] = 0.f, nmsc[qb] = 0.f, mlag[qb] = INFINITY;
     }
     if (nomax) {
         for (int tb = 0;; tb += 4) {

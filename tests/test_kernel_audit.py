@@ -1,0 +1,68 @@
+"""Static audit of the one-wave-per-SIMD attention kernels (attn64.hip, attn96.hip).  They address the accumulator half of the
+register file BY NAME from inline asm and list every accumulator register as clobbered; the moment hipcc runs out of VGPRs it
+uses accumulator registers as spill space regardless -- silent corruption of O^T.  The audit after every edit:
+compile to assembly for gfx950 (no GPU needed), then per kernel: no VGPR spills, no scratch, and no `v_accvgpr_*` instruction
+outside the `#ASMSTART ... #ASMEND` regions the source wrote itself.  Also: the generated slot tables are up to date."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "chipmunk_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _asm(tmp_path, name):
+    out = tmp_path / (name + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           os.path.join(CSRC, name + ".hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+@pytest.mark.parametrize("name,kernels", [("attn96", ["csp96_kernel"]), ("attn64", ["attn64_kernel", "colsum64_kernel"])])
+def test_named_accumulator_kernels_have_no_spills_and_no_compiler_accvgpr(tmp_path, name, kernels):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    text = _asm(tmp_path, name)
+    # ---- metadata: spills / scratch per kernel
+    meta = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", text, flags=re.S)
+    if not meta:   # field order differs between compiler versions: fall back to per-field scans
+        names = re.findall(r"^\s+\.name:\s+(\S+)", text, flags=re.M)
+        spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+        scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
+        meta = list(zip(names, scratch, spills))
+    checked = 0
+    for kname, scratch, spill in meta:
+        if any(k in kname for k in kernels):
+            assert int(spill) == 0, f"{kname}: {spill} VGPR spills (they land in the accumulator registers that hold O^T)"
+            assert int(scratch) == 0, f"{kname}: {scratch} bytes of scratch"
+            checked += 1
+    assert checked >= len(kernels), (checked, [m[0] for m in meta])
+    # ---- no accumulator moves the compiler made up
+    func, inasm, bad = None, False, []
+    for line in text.split("\n"):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            func = m.group(1)
+        if "#ASMSTART" in line:
+            inasm = True
+        elif "#ASMEND" in line:
+            inasm = False
+        elif "v_accvgpr" in line and not inasm and func and any(k in func for k in kernels):
+            bad.append((func, line.strip()))
+    assert not bad, f"compiler-generated accumulator moves: {bad[:4]} ... ({len(bad)} in all)"
+
+
+def test_attn96_slot_tables_are_current(tmp_path):
+    """attn96_sched.h is generated (tools/gen_attn96_sched.py asserts the ordering constraints of the schedule): the committed
+    header must be what the generator emits now."""
+    hdr = os.path.join(CSRC, "attn96_sched.h")
+    before = open(hdr).read()
+    try:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_attn96_sched.py")], stdout=subprocess.DEVNULL)
+        assert open(hdr).read() == before
+    finally:
+        open(hdr, "w").write(before)

@@ -49,3 +49,23 @@ with torch.no_grad():
         qk = hh[:, :2 * HID].view(-1, 2 * H, HID // H)
         print(f"   q/k rms_norm {t(lambda: torch.nn.functional.rms_norm(qk, (HID // H,))):.2f}  tokens_first {t(lambda: blk._tokens_first(o)):.2f}  "
               f"gated residual {t(lambda: torch.addcmul(x, m[2], x)):.2f}")
+
+    # q/k RMSNorm variants (the strided-view call above is what bench.py first used: 4.8 ms for 1.46 GB of q, k)
+    hh = torch.randn(N, 3 * HID + FFN, device=dev, dtype=torch.bfloat16)
+    v3 = hh.view(N, (3 * HID + FFN) // 128, 128)[:, :2 * H]
+    print(f"rms_norm on [N, 48, 128] strided view: {t(lambda: torch.nn.functional.rms_norm(v3, (128,))):.2f} ms")
+    c3 = v3.contiguous()
+    print(f"   contiguous copy {t(lambda: v3.contiguous()):.2f} + rms_norm contiguous {t(lambda: torch.nn.functional.rms_norm(c3, (128,))):.2f}")
+    w = torch.ones(128, device=dev, dtype=torch.bfloat16)
+    print(f"   rms_norm contiguous with weight {t(lambda: torch.nn.functional.rms_norm(c3, (128,), w, 1e-6)):.2f}")
+    def manual(x):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(x.dtype)
+    print(f"   manual fp32 chain {t(lambda: manual(v3)):.2f}")
+    try:
+        cm = torch.compile(manual)
+        cm(v3)
+        print(f"   torch.compile'd chain {t(lambda: cm(v3)):.2f}")
+    except Exception as e:
+        print("   torch.compile unavailable:", str(e)[:100])
+    print(f"layer_norm contiguous [N, 3072]: {t(lambda: torch.nn.functional.layer_norm(x, (HID,))):.2f}")
