@@ -319,54 +319,57 @@ class HunyuanBlock:
             self.lin1, self.lin2 = lin(hid, 3 * hid + ffn), lin(hid + ffn, hid)
         # shift / scale / gate vectors of the block's modulation (the model derives them from the timestep embedding)
         self.mod = [torch.randn(hid, **bf) * 0.02 for _ in range(6)]
-        self.cat = None
 
     @staticmethod
     def _ln_mod(x, shift, scale):
         xn = torch.nn.functional.layer_norm(x, (x.shape[-1],))
         return torch.addcmul(shift, xn, 1 + scale)
 
+    def _qk_norm(self, h):
+        """Projection output -> the attention's operands: split, q / k RMSNorm over the head dimension, head-major layout -- one
+        pass of chipmunk.qkv_split_norm (torch's rearrange + rms_norm x 2 + three transposes cost 8+ ms for these 2.2 GB,
+        tools/block_probe.py).  Run for its cost: attention consumes the synthetic q, k, v (see the module docstring)."""
+        import chipmunk_amd.ops as ops_pkg
+        ops_pkg.qkv_split_norm(h, None, None, self.heads, 1e-6)
+
     def pre(self, x):
-        """Everything in front of the attention; returns what post() needs (the fused linear1 output for single blocks)."""
+        """Everything in front of the attention; returns what post() needs (single-stream blocks: the MLP half of linear1)."""
         if not self.projections:
             return None
-        hid, H = self.hid, self.heads
+        hid = self.hid
         xm = self._ln_mod(x, self.mod[0], self.mod[1])
-        w = self.qkv if self.kind == "double" else self.lin1
-        h = torch.addmm(w.bias, xm, w.weight.t())
-        qk = h[:, :2 * hid].view(-1, 2 * H, hid // H)
-        torch.nn.functional.rms_norm(qk, (hid // H,))          # q / k norm: cost only, attention consumes the synthetic q, k, v
-        return h if self.kind == "single" else None
+        if self.kind == "double":
+            self._qk_norm(torch.addmm(self.qkv.bias, xm, self.qkv.weight.t()))
+            return None
+        # linear1 = [qkv | mlp] (reference models.py:373-376) as two GEMMs over views of the ONE fused weight: the MLP half gets its
+        # tanh-GELU in the GEMM epilogue instead of a separate pass over [rows, 12288] (2.6 ms), the result of the fused form
+        w, bias = self.lin1.weight, self.lin1.bias
+        self._qk_norm(torch.addmm(bias[:3 * hid], xm, w[:3 * hid].t()))
+        return torch._addmm_activation(bias[3 * hid:], xm, w[3 * hid:].t(), use_gelu=True)
 
-    def _tokens_first(self, o, out=None):
-        """Attention output -> [rows, hid] token-major (the reference's `b h s d -> b s (h d)`); into `out` if given."""
+    def _tokens_first(self, o):
+        """Attention output -> [rows, hid] token-major (the reference's `b h s d -> b s (h d)`)."""
         if o.dim() == 4:
             o = o[0].permute(1, 0, 2)                                  # [N, H, D] view of the head-major tensor
-            if out is None:
-                return o.reshape(o.shape[0], self.hid)
-            out.view(out.shape[0], self.heads, self.hid // self.heads).copy_(o)
-            return out
-        if out is None:
-            return o
-        out.copy_(o)
-        return out
+            return o.reshape(o.shape[0], self.hid)
+        return o
 
-    def post(self, x, h, attn):
+    def post(self, x, g, attn):
         """attn: the attention output, token-major [rows, hid] or head-major [1, H, rows, D]."""
-        hid, ffn = self.hid, self.ffn
+        hid = self.hid
         if not self.projections:
             return dense_mlp(x, self.fc1, self.fc2)
+        attn_flat = self._tokens_first(attn)
         if self.kind == "double":
-            attn_flat = self._tokens_first(attn)
             x = torch.addcmul(x, self.mod[2], torch.addmm(self.proj.bias, attn_flat, self.proj.weight.t()))
             xm = self._ln_mod(x, self.mod[3], self.mod[4])
             g = torch._addmm_activation(self.fc1.bias, xm, self.fc1.weight.t(), use_gelu=True)
             return torch.addcmul(x, self.mod[5], torch.addmm(self.fc2.bias, g, self.fc2.weight.t()))
-        if self.cat is None or self.cat.shape[0] != x.shape[0]:
-            self.cat = torch.empty(x.shape[0], hid + ffn, device=x.device, dtype=x.dtype)
-        self._tokens_first(attn, out=self.cat[:, :hid])
-        torch.ops.aten.gelu.out(h[:, 3 * hid:], approximate="tanh", out=self.cat[:, hid:])
-        return torch.addcmul(x, self.mod[2], torch.addmm(self.lin2.bias, self.cat, self.lin2.weight.t()))
+        # linear2 over cat(attn, gelu(mlp)) (reference :430) = attn @ W[:, :hid]^T + gelu(mlp) @ W[:, hid:]^T: no concatenated copy
+        w = self.lin2.weight
+        y = torch.addmm(self.lin2.bias, attn_flat, w[:, :hid].t())
+        y = torch.addmm(y, g, w[:, hid:].t())
+        return torch.addcmul(x, self.mod[2], y)
 
 
 def sdpa_backend_name():
@@ -722,9 +725,10 @@ class Hunyuan:
                 f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {blocks} (first 2 attention layers dense)",
                 "attention": "SparseDiffAttn, configs/hunyuan_c3.yml (full steps {0,1,10,40}, top 5% + 1% random + text columns, "
                              "bit-packed masks)",
-                "block": ("LayerNorm+modulate, QKV projection (fused linear1 in single-stream blocks), q/k RMSNorm, attention, output "
-                          "projection / linear2, gated residuals, MLP with tanh-GELU -- hipBLASLt GEMMs + torch elementwise ops, dense as "
-                          "in the reference (mlp.is_enabled: false); RoPE omitted") if not self.args.no_projections else
+                "block": ("LayerNorm+modulate, QKV projection, q/k norm, attention, output projection, gated residuals, MLP with tanh-GELU in "
+                          "fc1's epilogue (single-stream blocks: the fused linear1 / linear2 weights, computed as two GEMMs each over "
+                          "views, no concatenated copy) -- hipBLASLt GEMMs + torch elementwise ops, dense as in the reference "
+                          "(mlp.is_enabled: false); split + q/k RMSNorm + head-major layout by chipmunk.qkv_split_norm; RoPE omitted") if not self.args.no_projections else
                          "dense fc2(gelu_tanh(fc1(x))) per block (two hipBLASLt GEMMs)",
                 "attn_top_keys": self.cfg["attn"]["top_keys"], "step_caching": bool(self.cfg["step_caching"]["is_enabled"]),
                 "caches": "pinned-host offload" if self.args.offload else "resident in HBM (offloading.keep_resident_if_fits)",

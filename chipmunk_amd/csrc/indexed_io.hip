@@ -871,6 +871,63 @@ extern "C" int chipmunk_gather_rows(const void *src, void *dst, const int32_t *m
     return CHIPMUNK_OK;
 }
 
+// ---- QKV projection output -> attention operands: split + q/k RMSNorm + head-major layout in ONE pass.
+// The caller of the attention ops (reference examples/hunyuan/hyvideo/modules/models.py:188-193, 376-381) takes the projection's
+// [n, 3*H*128] output apart with rearrange("B L (K H D) -> K B L H D"), applies RMSNorm over the head dimension to q and k
+// (norm_layers.py:43-58: bf16(x_f32 * rsqrt(mean(x^2) + eps)) * weight, the product rounded to bf16 again) and transposes all
+// three to the [B, H, n, 128] operands the kernels take -- two norm passes and three transposing copies in torch (8+ ms for the
+// 2.2 GB of a HunyuanVideo layer).  Here: one 16-lane group per 256-byte (token, q|k|v, head) segment, 16 bytes per lane, the
+// sum of squares by DPP inside the group; reads are contiguous over the projection's rows, writes are whole 256-byte rows.
+__global__ __launch_bounds__(256) void qkv_split_norm_kernel(const uint16_t *qkv, int64_t row_stride, const uint16_t *qw,
+                                                             const uint16_t *kw, uint16_t *q, uint16_t *k, uint16_t *v, int64_t n,
+                                                             int H, float eps, int64_t segments) {
+    const int l15 = threadIdx.x & 15;
+    u32x4 wq = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, wk = wq;   // bf16 1.0 pairs
+    if (qw) wq = *(const u32x4 *)(qw + l15 * 8);
+    if (kw) wk = *(const u32x4 *)(kw + l15 * 8);
+    for (int64_t seg = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; seg < segments; seg += ((int64_t)gridDim.x * 256) >> 4) {
+        const int64_t tok = seg / (3 * H);
+        const int rem = (int)(seg - tok * 3 * H), which = rem / H, h = rem - which * H;
+        u32x4 x = *(const u32x4 *)(qkv + tok * row_stride + (int64_t)rem * 128 + l15 * 8);
+        uint16_t *dst = (which == 0 ? q : which == 1 ? k : v) + ((int64_t)h * n + tok) * 128 + l15 * 8;
+        if (which < 2) {   // (uniform over the 16-lane group; the DPP row sum only mixes lanes of one group)
+            float f[8], ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = __uint_as_float(x[e] << 16), f[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u);
+                ss = __builtin_fmaf(f[2 * e], f[2 * e], ss);
+                ss = __builtin_fmaf(f[2 * e + 1], f[2 * e + 1], ss);
+            }
+            ss = row16_sum(ss);
+            const float r = __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + eps);
+            const u32x4 w = which == 0 ? wq : wk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = f[2 * e] * r, b = f[2 * e + 1] * r;
+                round_bf16_pair(a, b);                                  // .type_as(x)
+                x[e] = pack_bf16x2(a * __uint_as_float(w[e] << 16), b * __uint_as_float(w[e] & 0xffff0000u));   // * weight, in bf16
+            }
+        }
+        *(u32x4 *)dst = x;
+    }
+}
+
+extern "C" int chipmunk_qkv_split_norm(const void *qkv, int64_t row_stride, const void *q_weight, const void *k_weight, void *q,
+                                       void *k, void *v, int64_t n, int heads, float eps, void *stream) {
+    CM_CHECK(qkv && q && k && v, "qkv_split_norm: null pointer");
+    CM_CHECK(n >= 0 && heads > 0 && row_stride >= (int64_t)3 * heads * 128, "qkv_split_norm: bad sizes");
+    CM_CHECK((((uintptr_t)qkv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)q_weight | (uintptr_t)k_weight) & 15) == 0 &&
+                 (row_stride & 7) == 0,
+             "qkv_split_norm: pointers and the row stride must be 16-byte aligned");
+    if (n == 0) return CHIPMUNK_OK;
+    const int64_t segments = n * 3 * heads, blocks = (segments + 15) / 16;
+    hipLaunchKernelGGL(qkv_split_norm_kernel, dim3((unsigned)(blocks > 256 * 64 ? 256 * 64 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)qkv, row_stride, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (uint16_t *)q,
+                       (uint16_t *)k, (uint16_t *)v, n, heads, eps, segments);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
 extern "C" int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void *static_mask, int64_t static_stride,
                                   int static_rows, const void *group_flags, void *mask, int rows, int n, int k,
                                   double random_amount, void *stream) {

@@ -501,6 +501,24 @@ at::Tensor bitunpack(at::Tensor packed, at::IntArrayRef shape) {
     return mask;
 }
 
+// [n, >= 3*heads*128] projection output -> q, k, v [1, heads, n, 128] with q/k RMSNorm (see chipmunk_qkv_split_norm)
+std::vector<at::Tensor> qkv_split_norm(at::Tensor qkv, const c10::optional<at::Tensor> &q_weight, const c10::optional<at::Tensor> &k_weight,
+                                       int64_t heads, double eps) {
+    CHECK_DEV(qkv); CHECK_BF16(qkv);
+    TORCH_CHECK(qkv.dim() == 2 && qkv.stride(1) == 1 && qkv.size(1) >= 3 * heads * 128, "qkv_split_norm: qkv must be [n, >= 3*heads*128] with a contiguous last dim");
+    const void *qw = nullptr, *kw = nullptr;
+    at::Tensor qwc, kwc;
+    if (q_weight.has_value() && q_weight->defined()) { qwc = q_weight->contiguous(); CHECK_DEV(qwc); CHECK_BF16(qwc); TORCH_CHECK(qwc.numel() == 128); qw = qwc.data_ptr(); }
+    if (k_weight.has_value() && k_weight->defined()) { kwc = k_weight->contiguous(); CHECK_DEV(kwc); CHECK_BF16(kwc); TORCH_CHECK(kwc.numel() == 128); kw = kwc.data_ptr(); }
+    const int64_t n = qkv.size(0);
+    c10::DeviceGuard guard(qkv.device());
+    at::Tensor out = at::empty({3, 1, heads, n, 128}, qkv.options());
+    check(chipmunk_qkv_split_norm(qkv.data_ptr(), qkv.stride(0), qw, kw, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), n,
+                                  (int)heads, (float)eps, cur_stream(qkv)),
+          "qkv_split_norm");
+    return {out[0], out[1], out[2]};
+}
+
 // dst[..., i, :] = src[..., map[i], :] over the second-to-last axis (token reorder; see chipmunk_gather_rows)
 at::Tensor gather_rows(at::Tensor src, at::Tensor map) {
     CHECK_DEV(src);
@@ -552,9 +570,11 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
     m.def("gather_rows(Tensor src, Tensor map) -> Tensor");
+    m.def("qkv_split_norm(Tensor qkv, Tensor? q_weight, Tensor? k_weight, int heads, float eps) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
+    m.impl("qkv_split_norm", &qkv_split_norm);
     m.impl("csp_mlp_mm1", &csp_mlp_mm1);
     m.impl("csp_mlp_mm2_and_scatter_add", &csp_mlp_mm2_and_scatter_add);
     m.impl("copy_indices", &copy_indices);

@@ -58,5 +58,10 @@ def _register():
         shape[-2] = map.shape[0]
         return src.new_empty(shape)
 
+    @lib.register_fake("chipmunk::qkv_split_norm")
+    def _(qkv, q_weight, k_weight, heads, eps):
+        out = qkv.new_empty((3, 1, heads, qkv.shape[0], 128))
+        return [out[0], out[1], out[2]]
+
 
 _register()

@@ -202,6 +202,14 @@ int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);
 int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t outer, int64_t n_src, int64_t n_out,
                          int64_t row_bytes, void *stream);
 
+/* ---------------------------------------------------------------- projection output -> attention operands
+ * qkv [n rows of row_stride elements, the first 3*heads*128 of each = (q|k|v, head, 128)] bf16  ->  q, k, v [heads, n, 128] bf16
+ * with RMSNorm over the 128 head elements applied to q and k: bf16(bf16(x * rsqrt(mean(x^2) + eps)) * weight); weights bf16
+ * [128] or NULL (= ones).  One pass instead of the caller's rearrange + two RMSNorm modules + three transposes
+ * (examples/hunyuan/hyvideo/modules/models.py:188-193,376-381; norm_layers.py:43-58). */
+int chipmunk_qkv_split_norm(const void *qkv, int64_t row_stride, const void *q_weight, const void *k_weight, void *q, void *k,
+                            void *v, int64_t n, int heads, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

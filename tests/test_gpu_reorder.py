@@ -93,3 +93,28 @@ def test_ops_trace_under_dynamo_without_graph_breaks(dev):
     eager = step(q, k, v, base, inds, counts)
     compiled = torch.compile(step, backend="eager", fullgraph=True)(q, k, v, base, inds, counts)
     assert torch.equal(eager[0], compiled[0]) and torch.equal(eager[1], compiled[1])
+
+
+@pytest.mark.parametrize("n,heads,extra,weights", [(1000, 24, 0, True), (4352, 24, 12288, True), (37, 3, 64, False), (1, 1, 0, True)])
+def test_qkv_split_norm_matches_the_reference_sequence(n, heads, extra, weights):
+    """chipmunk.qkv_split_norm = the caller's rearrange("B L (K H D) -> K B L H D") + RMSNorm(head_dim) on q and k
+    (reference hyvideo/modules/models.py:188-193, norm_layers.py:43-58) + the transposes to [B, H, L, D]; the input may be the
+    front part of a wider projection (single-stream blocks: linear1's 3*hidden + mlp columns).  v is a pure copy: bit-exact;
+    q, k: the hardware reciprocal square root may move a value by one bf16 step against torch's."""
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd.ops.qkv import qkv_split_norm
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    full = (torch.randn(n, 3 * heads * 128 + extra, generator=g) * 1.7).to(torch.bfloat16)
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(torch.bfloat16) if weights else None
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(torch.bfloat16) if weights else None
+    ref = qkv_split_norm(full, qw, kw, heads)                       # CPU: the reference's op sequence
+    got = qkv_split_norm(full.to(dev), None if qw is None else qw.to(dev), None if kw is None else kw.to(dev), heads)
+    torch.cuda.synchronize()
+    for name, r, o in zip("qkv", ref, got):
+        assert o.shape == (1, heads, n, 128) and o.is_contiguous()
+        if name == "v":
+            assert torch.equal(o.cpu(), r)
+        else:
+            torch.testing.assert_close(o.cpu().float(), r.float(), rtol=8e-3, atol=1e-6)     # one bf16 step
+            assert (o.cpu() == r).float().mean() > 0.98
