@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void qkv_split_norm_kernel(const uint16_t *qkv
                 ss = __builtin_fmaf(f[2 * e + 1], f[2 * e + 1], ss);
             }
             ss = row16_sum(ss);
-            const float r = __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + eps);
+            const float r = 1.0f / __builtin_sqrtf(ss * (1.0f / 128.0f) + eps);   // (IEEE sqrt and divide, as torch.rsqrt on the host)
             const u32x4 w = which == 0 ? wq : wk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -100,7 +100,8 @@ def test_qkv_split_norm_matches_the_reference_sequence(n, heads, extra, weights)
     """chipmunk.qkv_split_norm = the caller's rearrange("B L (K H D) -> K B L H D") + RMSNorm(head_dim) on q and k
     (reference hyvideo/modules/models.py:188-193, norm_layers.py:43-58) + the transposes to [B, H, L, D]; the input may be the
     front part of a wider projection (single-stream blocks: linear1's 3*hidden + mlp columns).  v is a pure copy: bit-exact;
-    q, k: the hardware reciprocal square root may move a value by one bf16 step against torch's."""
+    q, k: the sum of squares is added in another order than torch's, so a normalised value can land one bf16 step away, and the
+    weight product can round that into a second step (seen: 1 element in 3 million)."""
     import chipmunk_amd  # noqa: F401
     from chipmunk_amd.ops.qkv import qkv_split_norm
     dev = torch.device("cuda:0")
@@ -116,5 +117,5 @@ def test_qkv_split_norm_matches_the_reference_sequence(n, heads, extra, weights)
         if name == "v":
             assert torch.equal(o.cpu(), r)
         else:
-            torch.testing.assert_close(o.cpu().float(), r.float(), rtol=8e-3, atol=1e-6)     # one bf16 step
-            assert (o.cpu() == r).float().mean() > 0.98
+            torch.testing.assert_close(o.cpu().float(), r.float(), rtol=1.6e-2, atol=1e-6)   # two bf16 steps
+            assert (o.cpu() == r).float().mean() > 0.99
