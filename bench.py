@@ -252,6 +252,9 @@ def build_flux(dev, n_layers, timer):
     return step, dense_step, desc
 
 
+PMC_SUFFIX = ""     # workloads other than hunyuan_c3 / flux_c2 look for their own entries ("<op>" + suffix)
+
+
 def pmc_traffic(op_name):
     """HBM bytes per launch of the op's kernels from the committed PMC runs (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; regenerate with tools/collect_pmc_traffic.py).
@@ -259,8 +262,9 @@ def pmc_traffic(op_name):
     stamped into the line as roofline.traffic_source; (None, None) if no file has the op."""
     parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
              "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
-             "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"]}
-    keys = parts.get(op_name, [])
+             "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"],
+             "csp_mlp_mm1_fp8": ["mm1_fp8"]}
+    keys = [k + PMC_SUFFIX for k in parts.get(op_name, [])] if PMC_SUFFIX else parts.get(op_name, [])
     for fname in ("r03_pmc_traffic.json", "r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
@@ -913,6 +917,8 @@ def main():
         step, desc = wl.step, wl.desc()
         n_layers = wl.n_layers
     elif wan:
+        global PMC_SUFFIX
+        PMC_SUFFIX = "_wan"
         from tools.wan_workload import build_wan
         step, dense_step, desc, wan_extra = build_wan(dev, args, timer)
         n_layers = desc["layers"]
@@ -989,7 +995,7 @@ def main():
     roof = None
     if kernels:
         name, k = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
-        if hunyuan:   # ms-scale launches: the in-region HIP-event brackets ARE the launch durations (gaps ~ 10 us)
+        if hunyuan or wan:   # ms-scale launches: the in-region HIP-event brackets ARE the launch durations (gaps ~ 10 us)
             ms, flops, byts = k["avg_ms"], k["avg_flops"], k["avg_bytes"]
         else:
             ms, flops, byts = timer.probe(name)

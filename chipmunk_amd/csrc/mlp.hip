@@ -213,13 +213,24 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         const unsigned char *Bt = At + A_TILE;
         // operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are in flight while the
         // MFMAs of slice kk issue (left to itself hipcc emits read -> lgkmcnt(0) -> 4 MFMA -> read ...)
-        // one MFMA k slice = 16 elements: 32 bytes of a row in bf16 (16 per lane half), 16 bytes in fp8 (8 per half)
-        constexpr int KK = FP8 ? BK / 8 : BK / 16;
-        using Frag = typename std::conditional<FP8, long, bf16x8>::type;
+        // one MFMA k slice: bf16 = 16 elements (v_mfma_f32_32x32x16_bf16: 32 bytes of a row, 16 per lane half); fp8 = 64 elements
+        // (v_mfma_f32_32x32x64_f8f6f4, the K = 64 form that runs e4m3 at twice the bf16 rate -- the K = 16 fp8 MFMA runs at the
+        // bf16 rate: 64 bytes of a row, 32 per lane half = two 16-byte chunks, each swizzled on its own).  A and B fetch the same
+        // chunk positions of their rows, so the pairing of k elements inside the instruction is the same on both sides whatever
+        // order the hardware walks them in.
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        constexpr int KK = FP8 ? BK * 2 / 64 : BK / 16;
+        using Frag = typename std::conditional<FP8, i32x8, bf16x8>::type;
         Frag af[2][MT], bfr[2][NT4];
         auto frag = [&](const unsigned char *tile, int row, int kk) -> Frag {
-            if constexpr (FP8) return *(const long *)(tile + row * (BK * 2) + ((kk ^ KT::swz(row)) << 4) + ((lane >> 5) << 3));
-            else return KT::frag(tile, row, kk, lane);
+            if constexpr (FP8) {
+                const int c0 = kk * 4 + (lane >> 5) * 2;
+                const u32x4 lo = *(const u32x4 *)(tile + row * (BK * 2) + ((c0 ^ KT::swz(row)) << 4));
+                const u32x4 hi = *(const u32x4 *)(tile + row * (BK * 2) + (((c0 + 1) ^ KT::swz(row)) << 4));
+                return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            } else {
+                return KT::frag(tile, row, kk, lane);
+            }
         };
         auto load_frags = [&](int kk, int set) {
 #pragma unroll
@@ -236,8 +247,8 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int n4 = 0; n4 < NT4; ++n4) {
-                    if constexpr (FP8)
-                        acc[mt][n4] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4], 0, 0, 0);
+                    if constexpr (FP8)   // formats 0 / 0 = e4m3 x e4m3; literal zero scale operands select the unscaled encoding
+                        acc[mt][n4] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4], 0, 0, 0, 0, 0, 0);
                     else
                         acc[mt][n4] = mfma32(af[kk & 1][mt], bfr[kk & 1][n4], acc[mt][n4]);
                 }
