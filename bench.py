@@ -263,6 +263,7 @@ def pmc_traffic(op_name):
     parts = {"csp_mlp_mm1": ["mm1"], "csp_mlp_mm2_and_scatter_add": ["mm2", "scatter_add"], "csp_attn": ["csp_attn"],
              "csp_mlp_mm1+scatter_add": ["mm1+scatter_add"], "csp_mlp_mm2": ["mm2"],
              "csp_128_attn": ["csp_128_attn_c3"], "dense_attn": ["dense_attn_c3"], "dense_colsum_attn": ["dense_colsum_attn_c3"],
+             "dense_colsum_topk_mask": ["dense_colsum_topk_mask_c3"],
              "csp_mlp_mm1_fp8": ["mm1_fp8"]}
     keys = [k + PMC_SUFFIX for k in parts.get(op_name, [])] if PMC_SUFFIX else parts.get(op_name, [])
     for fname in ("r03_pmc_traffic.json", "r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
@@ -435,6 +436,9 @@ class Hunyuan:
                                           lambda q, k, v, o_in, indices, counts, o_scale: _csp128_work(q, k, v, indices, counts, extra=1))
         ops_pkg.dense_attn = timer.wrap("dense_attn", ops_pkg.dense_attn, _dense_work)
         ops_pkg.dense_colsum_attn = timer.wrap("dense_colsum_attn", ops_pkg.dense_colsum_attn, _colsum_work)
+        # the shipped mask step: the same pass + the top-k mask kernel reading its partial sums (no column-sum tensor)
+        ops_pkg.dense_colsum_topk_mask = timer.wrap("dense_colsum_topk_mask", ops_pkg.dense_colsum_topk_mask,
+                                                    lambda q, k, v, p, *a: _colsum_work(q, k, v, p))
         self.ops = ops_pkg
 
         self.vid = tuple(int(x) for x in args.grid.split(","))

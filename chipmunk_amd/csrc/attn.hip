@@ -755,12 +755,13 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // keys) / +5.4 % (keys shared between groups) over this file's kernel, but on HunyuanVideo's ragged launches (text /
     // tail groups 13x longer than the rest, one workgroup per CU) 15.5 vs 14.3 ms.
     // Gathered launches with at least three rounds of long items go to the two-waves-x-96-rows kernel of attn96.hip (same
-    // plan, same scratch): HunyuanVideo 24 heads +2 %, a head-parallel rank's 3 heads +6 %; short items (FLUX: 21 tiles) and
-    // single heads stay here (its per-item prologue and epilogue are longer).  Option attn_csp96: 1 = always, 2 = never.
+    // plan, same scratch): HunyuanVideo 24 heads 12.7 -> 11.1 ms, Wan2.1 (12 heads x 32 760 keys) 1.97 -> 1.67 ms; short items
+    // (FLUX: 21 tiles, 78 vs 130 us) and single heads stay here (its per-item prologue and epilogue are longer).  Option
+    // attn_csp96: 1 = always, 2 = never.
     const int o96 = chipmunk_get_option("attn_csp96");
     const bool fits96 = GATHER && !CSONLY && !WRITE_L && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24) &&
                         (p.idx_stride & 3) == 0;   // (its index rows are read 16 bytes at a time)
-    const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 6 * (int64_t)device_cu_count() && p.Nk >= 32768));
+    const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 6 * (int64_t)device_cu_count() && p.Nk >= 16384));
     const int o64 = chipmunk_get_option("attn_csp64");
     const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
@@ -984,11 +985,11 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
             // all (batch, head) pairs in one launch if the partial sums fit (21 GB at HunyuanVideo size), else in chunks of heads
             // -- halved until the buffer can be had, down to one head (0.9 GB)
             int hc = H;
-            float *part = nullptr;
+            uint16_t *part = nullptr;
             const int hc_min = chipmunk_get_option("attn_fused_colsum") == 4 ? 1 : 0;   // 4: one head per launch (test of the chunked form)
             if (hc_min) hc = 1;
             for (; hc >= 1; hc /= 2) {
-                part = (float *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(hc == H ? B : 1, hc, Nq, Nk));
+                part = (uint16_t *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(hc == H ? B : 1, hc, Nq, Nk));
                 if (part) break;
             }
             if (part && hc == H) return chipmunk_dense64_colsum_launch(p, part, st);
@@ -1015,4 +1016,40 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     // second pass: one wave per 192-row group where that fills the CUs (attn64.hip), the general kernel's K-only pass otherwise
     if (use_colsum64(B, H, Nq, Nk)) return chipmunk_colsum64_launch(p, st);
     return launch_attn<false, false, false, true>(p, st);
+}
+
+// dense attention + the mask-recompute step's key selection in one call: column sums stay in the per-wave partial rows of the
+// one-pass kernel (attn64.hip MODE 3) and the top-k mask kernel adds the three rows of a group itself -- the [B,H,G,Nk] `cs`
+// tensor of the reference (3.55 GB at HunyuanVideo size, written by dense_colsum_attn.cu:267-277 and re-read by
+// modules/attn.py:76-84) is never materialised.  Same bits as chipmunk_dense_colsum_attn followed by chipmunk_topk_mask.
+// Returns CHIPMUNK_ERR_UNSUPPORTED (nothing launched) when the launch does not take the one-pass route in one piece; the
+// caller then runs the two operators.
+extern "C" int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                               const int64_t k_strides[3], const int64_t v_strides[3], const float *pin, void *o,
+                                               float *l, int B, int H, int Nq, int Nk, const void *static_mask,
+                                               int64_t static_stride, int static_rows, const void *group_flags, void *mask,
+                                               int topk, double random_amount, void *stream) {
+    if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
+    CM_CHECK(l && pin && mask, "dense_colsum_topk_mask: p / l / mask missing");
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (!use_dense64(B, H, Nq, Nk) || chipmunk_get_option("attn_fused_colsum") == 2 || (Nk & 3) || Nk > 1024 * 120)
+        return CHIPMUNK_ERR_UNSUPPORTED;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
+    CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
+             "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
+    contiguous_strides(p.os, H, Nq);
+    p.l_out = l, p.p_in = pin, p.cs = nullptr, p.cs_stride = 0;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
+    p.o_scale = 1.f;
+    uint16_t *part = (uint16_t *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(B, H, Nq, Nk));
+    if (!part) return CHIPMUNK_ERR_UNSUPPORTED;
+    if (int e = chipmunk_dense64_colsum_launch(p, part, st)) return e;
+    const int nrb = ((Nq + 255) / 256) * 4;
+    return chipmunk_topk_mask_parts(part, nrb, p.G, Nq, static_mask, static_stride, static_rows, group_flags, mask, B * H * p.G, Nk,
+                                    topk, random_amount, st);
 }

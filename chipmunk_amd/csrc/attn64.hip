@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // the lane that ends up with key row (kb, u, rr, hf) of the tile: kb = bit 0, u = bit 1, rr = bits 4 3 2 (lsb first)
         const int rr = ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2);
-        csoff = 4u * (uint32_t)(32 * (lane & 1) + (rr & 3) + 8 * (2 * ((lane >> 1) & 1) + (rr >> 2)) + 4 * hf);
+        csoff = 2u * (uint32_t)(32 * (lane & 1) + (rr & 3) + 8 * (2 * ((lane >> 1) & 1) + (rr >> 2)) + 4 * hf);
         prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 4) + (g * 4 + w)) * p.Nk);
     }
     // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // last tile stores only its own keys, a padding tile nothing)
                 const int tb1 = tile_base(t - 1), dd = (t - 1) * KT - tb1;
                 if (t > 0 && dd < KT) {
-                    if (dd <= 0 || (int)(csoff >> 2) >= dd)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c5), prsrc, csoff, (uint32_t)tb1 * 4u, 0);
+                    if (dd <= 0 || (int)(csoff >> 1) >= dd)
+                        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pack_bf16x2(c5, 0.f) & 0xffffu), prsrc, csoff, (uint32_t)tb1 * 2u, 0);
                 }
             }
             if constexpr (!(A64_ABL & 16) && !GATHER && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
@@ -1023,29 +1023,36 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
 // sum_i P_ij w_i with the P the softmax pipeline has in registers anyway and w_i = exp2(m_i c) p_i (m = the reference
 // point).  S^T puts the queries on the lanes, so the sum over a wave's 64 queries is a 5-level reduce-scatter over the 32
 // lanes of a half (cs_pair*: 64 + 63 VALU operations per 64-key tile beside ~2 500 cycles of MFMA) instead of the second
-// pass's 96 MFMAs and 192 exponentials per 192 rows; every wave stores its 64 sums per tile into its own fp32 row and
-// cs_combine_kernel adds the three rows of a group (fixed order: the result does not depend on scheduling).
+// pass's 96 MFMAs and 192 exponentials per 192 rows; every wave stores its 64 sums per tile into its own bf16 row (fp32 rows
+// were 21 GB of traffic each way at HunyuanVideo size) and cs_combine_kernel -- or the top-k mask kernel itself, when the
+// caller only wants the mask -- adds the three rows of a group in fp32 (fixed order: the result does not depend on scheduling).
 namespace {
-__global__ __launch_bounds__(256) void cs_combine_kernel(const float *part, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
+__global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
     const int g = blockIdx.y, bh = blockIdx.z;
-    const float *src = part + ((int64_t)bh * NRB + 3 * g) * Nk;
+    const uint16_t *src = part + ((int64_t)bh * NRB + 3 * g) * Nk;
     uint16_t *dst = cs + ((int64_t)bh * G + g) * cs_stride;
     const int nrows = min(3, min(NRB - 3 * g, (Nq - 3 * g * 64 + 63) / 64));
     if (((Nk | cs_stride) & 3) == 0) {
         const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
         if (j >= Nk) return;
-        f32x4 acc = *(const f32x4 *)(src + j);
+        float acc[4];
+        {
+            const u32x2 x = *(const u32x2 *)(src + j);
+            acc[0] = __uint_as_float(x[0] << 16), acc[1] = __uint_as_float(x[0] & 0xffff0000u);
+            acc[2] = __uint_as_float(x[1] << 16), acc[3] = __uint_as_float(x[1] & 0xffff0000u);
+        }
         for (int r = 1; r < nrows; ++r) {
-            const f32x4 x = *(const f32x4 *)(src + (int64_t)r * Nk + j);
-            acc[0] += x[0], acc[1] += x[1], acc[2] += x[2], acc[3] += x[3];
+            const u32x2 x = *(const u32x2 *)(src + (int64_t)r * Nk + j);
+            acc[0] += __uint_as_float(x[0] << 16), acc[1] += __uint_as_float(x[0] & 0xffff0000u);
+            acc[2] += __uint_as_float(x[1] << 16), acc[3] += __uint_as_float(x[1] & 0xffff0000u);
         }
         *(u32x2 *)(dst + j) = (u32x2){pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
     } else {
         for (int e = 0; e < 4; ++e) {
             const int j = (blockIdx.x * 256 + threadIdx.x) * 4 + e;
             if (j >= Nk) return;
-            float acc = src[j];
-            for (int r = 1; r < nrows; ++r) acc += src[(int64_t)r * Nk + j];
+            float acc = bf16_bits_to_f32(src[j]);
+            for (int r = 1; r < nrows; ++r) acc += bf16_bits_to_f32(src[(int64_t)r * Nk + j]);
             dst[j] = f32_to_bf16_bits(acc);
         }
     }
@@ -1063,10 +1070,10 @@ int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
 }
 
 size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk) {
-    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)Nk * sizeof(float);
+    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)Nk * sizeof(uint16_t);
 }
 
-int chipmunk_dense64_colsum_launch(const AttnParams &p0, float *part, hipStream_t stream) {
+int chipmunk_dense64_colsum_launch(const AttnParams &p0, uint16_t *part, hipStream_t stream) {
     AttnParams p = p0;
     const int G192 = p.G;
     p.G = (p.Nq + WGROWS - 1) / WGROWS;
@@ -1074,6 +1081,7 @@ int chipmunk_dense64_colsum_launch(const AttnParams &p0, float *part, hipStream_
     if (chipmunk_get_option("attn_fused_colsum") == 3) p.probe |= 4;   // weighted column sums even where unit weights would do
     p.kmax = chipmunk_knorm_max(p.k, p.ks, p.B, p.H, p.Nk, stream);
     if (int rc = launch64<3>(p, (int64_t)p.B * p.H * p.G, stream)) return rc;
+    if (!p.cs) return CHIPMUNK_OK;   // the caller reads the partial rows itself (chipmunk_topk_mask_parts)
     hipLaunchKernelGGL(cs_combine_kernel, dim3((unsigned)((p.Nk + 1023) / 1024), (unsigned)G192, (unsigned)(p.B * p.H)), dim3(256), 0, stream,
                        part, p.cs, p.G * 4, G192, p.Nq, p.Nk, p.cs_stride);
     CM_LAUNCH_CHECK();

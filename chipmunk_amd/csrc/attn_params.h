@@ -29,8 +29,8 @@ struct AttnParams {
     // a wave can prove |s_ij| <= |q_i| * kmax for all its queries; if that bound is small enough for the exponent range, the
     // exponentials are taken against the FIXED reference point |q_i| * kmax and the running-maximum work disappears.
     const float *kmax;
-    // attn64.hip MODE 3 (dense + fused column sums): fp32 partial column sums, one row of Nk per (batch*head, 64-row wave block)
-    float *cs_part;
+    // attn64.hip MODE 3 (dense + fused column sums): bf16 partial column sums, one row of Nk per (batch*head, 64-row wave block)
+    uint16_t *cs_part;
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 
@@ -39,8 +39,14 @@ struct AttnParams {
 // accumulate forms (o_out = o_in + o_scale * result); `grid` = plan entries
 int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
 // attn64.hip: dense attention with the column sums of dense_colsum_attn folded into the same pass (p.p_in, p.cs, p.cs_stride
-// set; `part` = scratch of chipmunk_colsum_part_bytes(...) bytes), followed by the combine of the per-wave partial sums
-int chipmunk_dense64_colsum_launch(const AttnParams &p, float *part, hipStream_t stream);
+// set; `part` = scratch of chipmunk_colsum_part_bytes(...) bytes), followed -- when p.cs is set -- by the combine of the per-wave
+// partial sums into cs; with p.cs == nullptr the partial rows are the result (chipmunk_topk_mask_parts reads them)
+int chipmunk_dense64_colsum_launch(const AttnParams &p, uint16_t *part, hipStream_t stream);
+// indexed_io.hip: the top-k mask straight from the partial rows (row r of the mask = sum of rows 3r .. 3r+2 of `part` in its
+// (batch*head) block of `nrb` rows, rounded to bf16 -- exactly what the combine would have written)
+int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
+                             int static_rows, const void *group_flags, void *mask, int rows, int n, int k, double random_amount,
+                             hipStream_t stream);
 size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk);
 // attn64.hip: the column-sum pass of dense_colsum_attn for long launches (one wave per 192-row group)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);

@@ -17,7 +17,7 @@ extern "C" int chipmunk_abi_version(void) { return 1; }
 #include <string.h>
 namespace {
 struct Option { const char *name; int value; };
-Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}, {"attn_fused_colsum", 0}};
+Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}, {"attn_fused_colsum", 0}, {"big_scratch_gb", 0}};
 }
 int chipmunk_get_option(const char *name) {
     for (auto &o : g_options) if (strcmp(o.name, name) == 0) return o.value;
@@ -59,6 +59,7 @@ extern "C" int chipmunk_set_random_seed(uint64_t seed) {
 // zero).  Keyed by stream so that launches on different streams never share a buffer; launches on one stream are
 // ordered, which is all the users need.  A stream-ordered hipMallocAsync/hipFreeAsync pair per launch measured tens of
 // microseconds of host time -- more than the kernels it served.
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -89,26 +90,52 @@ void *chipmunk_scratch(hipStream_t stream, size_t bytes) {
     return ptr;
 }
 // A second, separately grown buffer for the one multi-GB user (the per-wave partial column sums of the fused
-// dense_colsum_attn pass: 21 GB at HunyuanVideo size).  Not zeroed; nullptr if the device cannot spare it (the caller then
-// takes the two-pass route).
+// dense_colsum_attn pass: 10.6 GB of bf16 at HunyuanVideo size).  Not zeroed; nullptr if the device cannot spare it (the
+// caller then takes smaller head chunks or the two-pass route).  The buffer lives outside torch's caching allocator, so it is
+// bounded: never more than option `big_scratch_gb` GiB (default 24) and never more than the free memory minus a 4 GiB
+// reserve at the time of the request; a size that failed is remembered, so failing hipMallocs are not retried on every call;
+// chipmunk_release_scratch() gives everything back.
+namespace {
+std::map<std::pair<int, hipStream_t>, Scratch> g_big;
+std::map<int, size_t> g_big_failed;   // per device: smallest request that could not be served
+}
 void *chipmunk_big_scratch(hipStream_t stream, size_t bytes) {
-    static std::map<std::pair<int, hipStream_t>, Scratch> big;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    Scratch &s = big[{dev, stream}];
+    Scratch &s = g_big[{dev, stream}];
     if (s.bytes >= bytes) return s.ptr;
-    if (s.ptr) {
-        (void)hipStreamSynchronize(stream);
-        (void)hipFree(s.ptr);
-        s.ptr = nullptr, s.bytes = 0;
-    }
+    const int cap_gb = chipmunk_get_option("big_scratch_gb");
+    const size_t cap = (size_t)(cap_gb > 0 ? cap_gb : 24) << 30;
     const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-    void *ptr = nullptr;
-    if (hipMalloc(&ptr, want) != hipSuccess) {
-        (void)hipGetLastError();
+    if (want > cap) return nullptr;
+    auto f = g_big_failed.find(dev);
+    if (f != g_big_failed.end() && want >= f->second) return nullptr;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b + s.bytes - std::min(free_b + s.bytes, (size_t)4 << 30)) {
+        g_big_failed[dev] = f == g_big_failed.end() ? want : std::min(f->second, want);
         return nullptr;
     }
+    void *ptr = nullptr;
+    if (s.ptr) (void)hipStreamSynchronize(stream);   // earlier launches on this stream may still be using the old buffer
+    if (hipMalloc(&ptr, want) != hipSuccess) {
+        (void)hipGetLastError();
+        g_big_failed[dev] = f == g_big_failed.end() ? want : std::min(f->second, want);
+        return nullptr;                               // (the smaller buffer, if any, stays)
+    }
+    if (s.ptr) (void)hipFree(s.ptr);
     s.ptr = ptr, s.bytes = want;
     return ptr;
+}
+extern "C" int chipmunk_release_scratch(void) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_big)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_big.clear();
+    g_big_failed.clear();
+    for (auto &kv : g_scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_scratch.clear();
+    return CHIPMUNK_OK;
 }

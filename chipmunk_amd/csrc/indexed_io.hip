@@ -547,13 +547,17 @@ struct TopkMaskParams {
     int rows, n, k, stat_rows;
     float random_amount;
     uint32_t salt;           // per-launch value, see chipmunk_next_random_salt
+    // PARTS form: row r of "cs" = bf16(sum of rows 3g .. 3g+2 of the partial rows of its (batch*head) block), g = r % groups
+    const uint16_t *parts;
+    int nrb, ngroups, nq;    // partial rows per (batch*head); 192-row groups per (batch*head); query rows
 };
 
 __device__ __forceinline__ uint32_t bf16_key(uint32_t u) {  // monotone bf16 bits -> u16 (larger value = larger key)
     return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
 }
 
-template <int KPT, bool ALIGNED>  // keys per thread (multiple of 4); the row must have n <= 1024 * KPT columns.
+template <int KPT, bool ALIGNED, bool PARTS = false>  // keys per thread (multiple of 4); the row must have n <= 1024 * KPT columns.
+// PARTS (ALIGNED only): the row's column sums are not in memory; they are the sum of up to three bf16 partial rows (see above)
 // ALIGNED: n % 4 == 0 and every row of cs / static mask / mask starts on an 8 / 4 / 4-byte boundary, so each thread
 // step is one 8-byte load, one 4-byte load and one 4-byte store; the generic form goes element by element.
 __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p) {
@@ -561,8 +565,16 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     __shared__ int wave_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x;
-    const uint16_t *x = p.cs + (int64_t)row * p.cs_stride;
     const int n = p.n;
+    const uint16_t *x = nullptr;
+    int prow = 1;
+    if constexpr (PARTS) {
+        const int bh = row / p.ngroups, g = row - bh * p.ngroups;
+        x = p.parts + ((int64_t)bh * p.nrb + 3 * g) * n;
+        prow = min(3, min(p.nrb - 3 * g, (p.nq - 3 * g * 64 + 63) / 64));
+    } else {
+        x = p.cs + (int64_t)row * p.cs_stride;
+    }
     const uint32_t lane_off8 = 8u * (uint32_t)tid;    // byte offset of this thread's 4 bf16 inside a 4096-column step
     const uint32_t lane_off4 = 4u * (uint32_t)tid;    // ... of its 4 mask bytes
     // columns 4*tid + 4096*j .. +3; columns past n read as bf16 bits 0xffff = key 0, below every real key
@@ -582,6 +594,16 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
                     // wave-uniform base + one shared 32-bit lane offset: the saddr form, no 64-bit address per step
                     const u32x2 v = *(const u32x2 *)((const unsigned char *)(x + 4096 * (j0 + jj)) + lane_off8);
                     v0 = v[0], v1 = v[1];
+                    if constexpr (PARTS) {   // the combine, in its order: (row 0 + row 1) + row 2 in fp32, one rounding to bf16
+                        float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
+                        float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
+                        for (int r = 1; r < prow; ++r) {
+                            const u32x2 y = *(const u32x2 *)((const unsigned char *)(x + (int64_t)r * n + 4096 * (j0 + jj)) + lane_off8);
+                            a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
+                            a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
+                        }
+                        v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
+                    }
                 }
             } else if (c < n) {
                 v0 = v1 = 0;
@@ -681,7 +703,28 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     uint8_t *out = p.mask + (int64_t)row * n;
     const uint8_t *st = p.stat ? p.stat + (int64_t)(row % p.stat_rows) * p.stat_stride : nullptr;
     const bool rnd = active && p.random_amount > 0.f;
-    const uint32_t salt = p.salt ^ ((uint32_t)x[0] * 0x27D4EB2Fu);
+    // (PARTS: the combined value at column c0..c0+3 again, same order of additions as in the selection pass)
+    auto combined4 = [&](int c0, uint32_t &v0, uint32_t &v1) {
+        const u32x2 v = *(const u32x2 *)(x + c0);
+        v0 = v[0], v1 = v[1];
+        if constexpr (PARTS) {
+            float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
+            float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
+            for (int r = 1; r < prow; ++r) {
+                const u32x2 y = *(const u32x2 *)(x + (int64_t)r * n + c0);
+                a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
+                a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
+            }
+            v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
+        }
+    };
+    uint32_t first = x[0];
+    if constexpr (PARTS) {
+        uint32_t f0, f1;
+        combined4(0, f0, f1);
+        first = f0 & 0xffffu;
+    }
+    const uint32_t salt = p.salt ^ (first * 0x27D4EB2Fu);
     const int nsteps = (n + 4095) / 4096;
 #pragma unroll 2
     for (int j = 0; j < nsteps; ++j) {
@@ -689,8 +732,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
         if (c >= n) break;
         uint32_t v0 = 0, v1 = 0, sb = 0;
         if constexpr (ALIGNED) {
-            const u32x2 v = *(const u32x2 *)(x + c);
-            v0 = v[0], v1 = v[1];
+            combined4(c, v0, v1);
             if (st) sb = *(const uint32_t *)(st + c);
         } else {
 #pragma unroll
@@ -867,6 +909,25 @@ extern "C" int chipmunk_gather_rows(const void *src, void *dst, const int32_t *m
     else if ((align & 1) == 0) LAUNCH_GATHER(uint16_t);
     else LAUNCH_GATHER(uint8_t);
 #undef LAUNCH_GATHER
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
+                             int static_rows, const void *group_flags, void *mask, int rows, int n, int k, double random_amount,
+                             hipStream_t s) {
+    CM_CHECK(part && mask && rows >= 0 && n > 0 && (n & 3) == 0 && n <= 1024 * 120 && k >= 0, "topk_mask_parts: bad arguments");
+    CM_CHECK(!static_mask || (static_rows > 0 && static_stride >= n && (static_stride & 3) == 0 && ((uintptr_t)static_mask & 3) == 0),
+             "topk_mask_parts: bad static mask geometry");
+    CM_CHECK(((uintptr_t)mask & 3) == 0 && ((uintptr_t)part & 7) == 0, "topk_mask_parts: unaligned buffers");
+    if (rows == 0) return CHIPMUNK_OK;
+    TopkMaskParams p = {nullptr, (const uint8_t *)static_mask, (const uint8_t *)group_flags, (uint8_t *)mask, 0, static_stride,
+                        rows, n, k, static_mask ? static_rows : 1, (float)random_amount,
+                        random_amount > 0.0 ? chipmunk_next_random_salt() : 0u};
+    p.parts = part, p.nrb = nrb, p.ngroups = groups_per_bh, p.nq = Nq;
+    if (n <= 1024 * 16) hipLaunchKernelGGL((topk_mask_kernel<16, true, true>), dim3(rows), dim3(1024), 0, s, p);
+    else if (n <= 1024 * 48) hipLaunchKernelGGL((topk_mask_kernel<48, true, true>), dim3(rows), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((topk_mask_kernel<120, true, true>), dim3(rows), dim3(1024), 0, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

@@ -147,16 +147,18 @@ std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor
     TORCH_CHECK(p.scalar_type() == at::kFloat, "p must be float32");
     TORCH_CHECK(p.is_contiguous(), "p must be contiguous");
     TORCH_CHECK(p.numel() == q.size(0) * q.size(1) * q.size(2), "p must have one entry per query row [B,H,N,1]");
-    TORCH_CHECK(k.size(2) <= q.size(2), "column sums have one column per (padded) query position: Nk must be <= Nq");
     c10::DeviceGuard guard(q.device());
     auto qs = strides_of(q, "Q"), ks = strides_of(k, "K"), vs = strides_of(v, "V");
     const int64_t groups = (q.size(2) + 191) / 192;
+    // the reference's cs has one column per (padded) query position (:580-583: it only ever sees Nk <= Nq); a rank that holds a
+    // slice of the query rows against the whole sequence's keys (query-group sharding) gets one column per key
+    const int64_t width = std::max<int64_t>(q.size(2), k.size(2));
     at::Tensor o = at::empty(q.sizes(), v.options().memory_format(at::MemoryFormat::Contiguous));
-    at::Tensor cs = at::empty({q.size(0), q.size(1), groups, q.size(2)}, v.options());  // :580-583
+    at::Tensor cs = at::empty({q.size(0), q.size(1), groups, width}, v.options());
     at::Tensor l = at::empty({q.size(0), q.size(1), q.size(2), 1}, q.options().dtype(at::kFloat));
     check(chipmunk_dense_colsum_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs.s, ks.s, vs.s, p.data_ptr<float>(),
                                      o.data_ptr(), cs.data_ptr(), l.data_ptr<float>(), (int)q.size(0), (int)q.size(1),
-                                     (int)q.size(2), (int)k.size(2), (int)q.size(2), cur_stream(q)),
+                                     (int)q.size(2), (int)k.size(2), (int)width, cur_stream(q)),
           "dense_colsum_attn");
     return {o, cs, l};
 }
@@ -443,6 +445,60 @@ std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef 
 }
 
 // addition: randint + topk + scatter_ + the two mask combines of modules/attn.py:76-82 in one kernel
+// dense_colsum_attn + topk_mask without the cs tensor between them (see chipmunk_dense_colsum_topk_mask); falls back to the two
+// operators when the fused entry does not apply to the launch
+std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p);
+at::Tensor topk_mask(at::Tensor cs, int64_t k, double random_amount, const c10::optional<at::Tensor> &groups,
+                     const c10::optional<at::Tensor> &static_mask);
+std::vector<at::Tensor> dense_colsum_topk_mask(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p, int64_t k_top, double random_amount,
+                                               const c10::optional<at::Tensor> &groups, const c10::optional<at::Tensor> &static_mask) {
+    CHECK_DEV(q); CHECK_DEV(k); CHECK_DEV(v); CHECK_DEV(p);
+    CHECK_BF16(q); CHECK_BF16(k); CHECK_BF16(v);
+    const bool shapes_ok = q.dim() == 4 && k.dim() == 4 && v.dim() == 4 && q.size(3) == 128 && q.stride(3) == 1 && k.stride(3) == 1 &&
+                           v.stride(3) == 1 && p.scalar_type() == at::kFloat && p.is_contiguous();
+    if (shapes_ok) {
+        const int64_t B = q.size(0), H = q.size(1), Nq = q.size(2), Nk = k.size(2), G = (Nq + 191) / 192;
+        const void *st = nullptr, *gf = nullptr;
+        int64_t st_stride = 0, st_rows = 1;
+        at::Tensor stc, gfc;
+        bool ok = p.numel() == B * H * Nq;
+        if (ok && static_mask.has_value() && static_mask->defined()) {
+            stc = *static_mask;
+            ok = stc.is_cuda() && stc.scalar_type() == at::kBool && stc.dim() == 4 && stc.size(3) == Nk && stc.size(2) == G && stc.size(1) == H &&
+                 (stc.size(0) == 1 || stc.size(0) == B) && stc.stride(3) == 1 && stc.stride(1) == G * stc.stride(2) &&
+                 (stc.size(0) == 1 || stc.stride(0) == H * stc.stride(1));
+            if (ok) st = stc.data_ptr(), st_stride = stc.stride(2), st_rows = stc.size(0) * H * G;
+        }
+        if (ok && groups.has_value() && groups->defined()) {
+            gfc = *groups;
+            ok = gfc.is_cuda() && gfc.scalar_type() == at::kBool && gfc.dim() == 4 && gfc.size(3) == 1 && gfc.size(2) == G && gfc.size(1) == H &&
+                 (gfc.size(0) == 1 || gfc.size(0) == B);
+            if (ok) {
+                gfc = gfc.expand({B, H, G, 1}).contiguous();
+                gf = gfc.data_ptr();
+            }
+        }
+        if (ok) {
+            c10::DeviceGuard guard(q.device());
+            at::Tensor o = at::empty({B, H, Nq, 128}, q.options());
+            at::Tensor l = at::empty({B, H, Nq, 1}, q.options().dtype(at::kFloat));
+            at::Tensor mask = at::empty({B, H, G, Nk}, q.options().dtype(at::kBool));
+            const int64_t qs[3] = {q.stride(0), q.stride(1), q.stride(2)}, ks[3] = {k.stride(0), k.stride(1), k.stride(2)},
+                          vs[3] = {v.stride(0), v.stride(1), v.stride(2)};
+            const int rc = chipmunk_dense_colsum_topk_mask(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs, ks, vs, p.data_ptr<float>(), o.data_ptr(),
+                                                           l.data_ptr<float>(), (int)B, (int)H, (int)Nq, (int)Nk, st, st_stride, (int)st_rows, gf,
+                                                           mask.data_ptr(), (int)k_top, random_amount, cur_stream(q));
+            if (rc == CHIPMUNK_OK) return {o, mask, l};
+            if (rc != CHIPMUNK_ERR_UNSUPPORTED) check(rc, "dense_colsum_topk_mask");
+        }
+    }
+    auto ocl = dense_colsum_attn(q, k, v, p);
+    at::Tensor cs = ocl[1];
+    const int64_t Nk = k.size(2), G = (q.size(2) + 191) / 192;
+    if (cs.size(-1) != Nk || cs.size(-2) != G) cs = cs.slice(-2, 0, G).slice(-1, 0, Nk);
+    return {ocl[0], topk_mask(cs, k_top, random_amount, groups, static_mask), ocl[2]};
+}
+
 at::Tensor topk_mask(at::Tensor cs, int64_t k, double random_amount, const c10::optional<at::Tensor> &groups,
                      const c10::optional<at::Tensor> &static_mask) {
     CHECK_DEV(cs); CHECK_BF16(cs);
@@ -566,6 +622,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("mask_to_sorted_indices(Tensor mask, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("topk_mask(Tensor cs, int k, float random_amount, Tensor? groups, Tensor? static_mask) -> Tensor");
+    m.def("dense_colsum_topk_mask(Tensor q, Tensor k, Tensor v, Tensor p, int k_top, float random_amount, Tensor? groups, Tensor? static_mask) -> Tensor[]");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -575,6 +632,7 @@ TORCH_LIBRARY(chipmunk, m) {
 
 TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("qkv_split_norm", &qkv_split_norm);
+    m.impl("dense_colsum_topk_mask", &dense_colsum_topk_mask);
     m.impl("csp_mlp_mm1", &csp_mlp_mm1);
     m.impl("csp_mlp_mm2_and_scatter_add", &csp_mlp_mm2_and_scatter_add);
     m.impl("copy_indices", &copy_indices);

@@ -130,15 +130,23 @@ class SparseDiffAttn(nn.Module):
 
             if inference_step == 1 or cfg["recompute_mask"]:
                 prev_lse = self.storage.get_lse_constants()
-                if do_padding:
+                tk = int(multiple_of * round((cfg["top_keys"] * k.shape[-2]) / multiple_of))
+                mask = bs = None
+                if (q.is_cuda and cfg["should_compress_indices"] and tk > 0 and amd_key("attn", "fused_colsum_topk")
+                        and amd_key("attn", "fused_topk_mask") and k.shape[-2] <= 122880):
+                    # dense attention -> column sums -> mask without the column-sum tensor in between (same bits as the two steps)
+                    static, groups = self._static(q.shape[1], _cdiv(q.shape[-2], bm), k.shape[-2])
+                    o, mask, lse = ops.dense_colsum_topk_mask(q, k, v, prev_lse, tk, 0.01, groups, static)
+                elif do_padding:
                     o, bs, lse = ops.dense_colsum_attn(q, k, v, prev_lse)
                 else:
                     o, bs, lse = torch.ops.chipmunk.dense_colsum_attn(q, k, v, prev_lse)
                 lse[..., k.shape[-2]:, :] = 0
                 self.storage.set_lse_constants(lse)
-                tk = int(multiple_of * round((cfg["top_keys"] * k.shape[-2]) / multiple_of))
                 if cfg["should_compress_indices"]:
-                    if tk > 0:
+                    if mask is not None:
+                        pass
+                    elif tk > 0:
                         mask = self.random_and_topk(bs, tk)
                     else:
                         mask = self._static(bs.shape[1], bs.shape[-2], bs.shape[-1])[0]

@@ -58,6 +58,13 @@ def _register():
         shape[-2] = map.shape[0]
         return src.new_empty(shape)
 
+    @lib.register_fake("chipmunk::dense_colsum_topk_mask")
+    def _(q, k, v, p, k_top, random_amount, groups, static_mask):
+        B, H, Nq, D = q.shape
+        G = (Nq + 191) // 192
+        return [q.new_empty((B, H, Nq, D)), q.new_empty((B, H, G, k.shape[2]), dtype=torch.bool),
+                q.new_empty((B, H, Nq, 1), dtype=torch.float32)]
+
     @lib.register_fake("chipmunk::qkv_split_norm")
     def _(qkv, q_weight, k_weight, heads, eps):
         out = qkv.new_empty((3, 1, heads, qkv.shape[0], 128))

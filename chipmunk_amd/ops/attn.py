@@ -54,6 +54,21 @@ def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torc
     return o, cs, l
 
 
+def dense_colsum_topk_mask(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torch.Tensor, k_top: int, random_amount: float,
+                           groups, static_mask) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``dense_colsum_attn`` followed by ``topk_mask`` on its column sums, without the ``[..., ceil(N/192), N]`` tensor between
+    them (reference ``modules/attn.py:131-141``: 3.55 GB per HunyuanVideo layer).  Returns ``(o, mask, l padded)`` -- the same
+    bits as the two calls.  GPU only (CPU tensors take the reference's op sequence in the module)."""
+    n = q.shape[-2]
+    padded = _pad_len(n)
+    assert p.shape[-2] in (n, padded), "p must be the l vector of the previous full step"
+    o, mask, l = torch.ops.chipmunk.dense_colsum_topk_mask(_last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v),
+                                                           p[..., :n, :].contiguous(), k_top, random_amount, groups, static_mask)
+    if padded != n:
+        l = F.pad(l, (0, 0, 0, padded - n))
+    return o, mask, l
+
+
 def csp_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, indices: torch.Tensor,
              indices_counts: torch.Tensor) -> torch.Tensor:
     """Out-of-place column-sparse attention (reference ``ops/attn.py:134-169`` -> ``csp_128_attn``)."""
@@ -75,4 +90,4 @@ def csp_attn_out(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o_in: torch.
     return torch.ops.chipmunk.csp_attn_out(q, k, v, o_in, indices, indices_counts, o_scale)
 
 
-__all__ = ["csp_attn", "csp_attn_inplace", "csp_attn_out", "dense_attn", "dense_colsum_attn"]
+__all__ = ["csp_attn", "csp_attn_inplace", "csp_attn_out", "dense_attn", "dense_colsum_attn", "dense_colsum_topk_mask"]

@@ -87,6 +87,8 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "attn.fused_residual": True,
     # mask-building step: randint + topk + scatter_ + mask combines of `random_and_topk` as one kernel
     "attn.fused_topk_mask": True,
+    # mask-building step: dense_colsum_attn + the mask kernel without the [.., N/192, N] column-sum tensor between them
+    "attn.fused_colsum_topk": True,
     # sparse MLP step: GEMM1 applies the scatter-add of its own output (one kernel less, no re-read of c / the cache)
     "mlp.fused_scatter": True,
 }
@@ -97,6 +99,7 @@ BASE_CONFIG["attn"]["sorted_indices"] = AMD_EXTRA_KEYS["attn.sorted_indices"]
 BASE_CONFIG["mlp"]["fused_topk_delta"] = AMD_EXTRA_KEYS["mlp.fused_topk_delta"]
 BASE_CONFIG["attn"]["fused_residual"] = AMD_EXTRA_KEYS["attn.fused_residual"]
 BASE_CONFIG["attn"]["fused_topk_mask"] = AMD_EXTRA_KEYS["attn.fused_topk_mask"]
+BASE_CONFIG["attn"]["fused_colsum_topk"] = AMD_EXTRA_KEYS["attn.fused_colsum_topk"]
 BASE_CONFIG["mlp"]["fused_scatter"] = AMD_EXTRA_KEYS["mlp.fused_scatter"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)

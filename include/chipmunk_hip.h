@@ -27,6 +27,7 @@ extern "C" {
 #define CHIPMUNK_OK 0
 #define CHIPMUNK_ERR_INVALID 1 /* bad shape / argument (the reference raises TORCH_CHECK / std::runtime_error) */
 #define CHIPMUNK_ERR_LAUNCH 2  /* HIP launch failure */
+#define CHIPMUNK_ERR_UNSUPPORTED 3 /* a fused entry point that does not apply to this launch: nothing was enqueued, use the unfused operators */
 
 /* element types for the dtype-generic ops (reference dispatches bf16/fp16/fp32: topk_indices.cu:171-215) */
 #define CHIPMUNK_DTYPE_BF16 0
@@ -82,8 +83,9 @@ int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64
  *   cs[b,h,g,j] = sum_{i in group g} bf16(exp(s_ij - m_i)) * bf16(exp(m_i) * p_i)   for j < Nk
  * (dense_colsum_attn.cu:267-277); columns j >= Nk are left untouched.
  * Launches that fill the CUs run as ONE pass (the column sums ride the dense kernel's softmax pipeline) and keep, per
- * (device, stream), a library-owned buffer of fp32 partial sums of B*H*ceil(Nq/256)*4*Nk*4 bytes (halved per chunk of
- * heads if that cannot be allocated); the first call on a stream allocates it, so call once before capturing a graph. */
+ * (device, stream), a library-owned buffer of bf16 partial sums of B*H*ceil(Nq/256)*4*Nk*2 bytes (halved per chunk of
+ * heads if that cannot be allocated; bounded, see chipmunk_release_scratch); the first call on a stream allocates it, so call
+ * once before capturing a graph. */
 int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
                                const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
                                void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride, void *stream);
@@ -152,6 +154,16 @@ int chipmunk_topk_delta_indices(const void *activation, void *cache, int dtype, 
                                 int rows, int cols, double sparsity_amount, int multiple_of, double random_amount,
                                 void *stream);
 
+/* chipmunk_dense_colsum_attn + chipmunk_topk_mask without the cs tensor between them (reference modules/attn.py:131-141 calls
+ * dense_colsum_attn, then random_and_topk on its 3.55 GB result at HunyuanVideo size): o, l as chipmunk_dense_colsum_attn,
+ * mask [B*H*ceil(Nq/192), Nk] bool bytes as chipmunk_topk_mask would produce from that call's cs -- bit for bit.
+ * Returns CHIPMUNK_ERR_UNSUPPORTED without enqueuing anything when the launch would not take the one-pass route in one piece
+ * (small launches, Nk % 4 != 0, no room for the partial sums): run the two operators then. */
+int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                    const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o, float *l,
+                                    int B, int H, int Nq, int Nk, const void *static_mask, int64_t static_stride, int static_rows,
+                                    const void *group_flags, void *mask, int k_top, double random_amount, void *stream);
+
 /* Fused mask construction of the attention mask-building step (reference
  * src/chipmunk/modules/attn.py:76-82 `random_and_topk`):
  *   mask[r, c] = ((c in topk_k(cs[r, :n])) | (u(r, c) < random_amount)) & group_flags[r]  |  static_mask[r % static_rows, c]
@@ -201,6 +213,10 @@ int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);
  * (src/chipmunk/ops/voxel.py:9-99) -- whose permutations the host side computes once per shape. `map` int32 [n_out]. */
 int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t outer, int64_t n_src, int64_t n_out,
                          int64_t row_bytes, void *stream);
+
+/* Gives back the library's device scratch (work plans, split partials, the multi-GB partial column sums of the fused
+ * dense_colsum_attn pass -- bounded by option "big_scratch_gb", default 24).  Synchronises the device. */
+int chipmunk_release_scratch(void);
 
 /* ---------------------------------------------------------------- projection output -> attention operands
  * qkv [n rows of row_stride elements, the first 3*heads*128 of each = (q|k|v, head, 128)] bf16  ->  q, k, v [heads, n, 128] bf16

@@ -413,3 +413,40 @@ def test_long_launch_kernels_are_hipgraph_capturable(dev):
     finally:
         for o in opts:
             _native.set_option(o, 0)
+
+
+@pytest.mark.parametrize("n,nk,heads", [(1536, 1536, 4), (1000, 1000, 3), (2304, 2304, 2), (960, 2304, 2)])
+def test_fused_mask_step_equals_colsum_then_topk_mask(dev, n, nk, heads):
+    """chipmunk.dense_colsum_topk_mask (the mask-recompute step without the column-sum tensor: the mask kernel adds the three
+    bf16 partial rows of a group itself) against dense_colsum_attn followed by topk_mask: o, l and the mask bit for bit --
+    ragged last groups, fewer query rows than keys (query-group sharding), static mask and group flags; and both against the
+    oracle's column sums."""
+    import math
+    from chipmunk_amd import _native
+    from chipmunk_amd import ops
+    G = math.ceil(n / 192)
+    q = randn_bf16(1, heads, n, 128, seed=n + 1).to(dev)
+    k = randn_bf16(1, heads, nk, 128, seed=nk + 2).to(dev)
+    v = randn_bf16(1, heads, nk, 128, seed=nk + 3).to(dev)
+    gen = torch.Generator().manual_seed(7)
+    static = (torch.rand(1, heads, G, nk, generator=gen) < 0.02).to(dev)
+    groups = (torch.rand(1, heads, G, 1, generator=gen) < 0.8).to(dev)
+    ktop = 128
+    for opt in ("attn_dense64", "attn_colsum64"):
+        _native.set_option(opt, 1)
+    try:
+        _, l0 = ops.dense_attn(q, k, v)
+        o_a, cs, l_a = ops.dense_colsum_attn(q, k, v, l0)
+        cs = cs[..., :G, :nk]
+        m_a = ops.topk_mask(cs, ktop, 0.0, groups, static)
+        o_b, m_b, l_b = ops.dense_colsum_topk_mask(q, k, v, l0, ktop, 0.0, groups, static)
+        torch.cuda.synchronize()
+    finally:
+        for opt in ("attn_dense64", "attn_colsum64"):
+            _native.set_option(opt, 0)
+    assert torch.equal(o_a, o_b) and torch.equal(l_a, l_b)
+    assert m_b.shape == (1, heads, G, nk) and torch.equal(m_a, m_b)
+    assert (m_b.sum(-1)[groups[..., 0]] >= ktop).all()
+    if n == nk:   # (the oracle's cs has Nq columns)
+        cs_ref = oracle.dense_colsum_attn(q.cpu(), k.cpu(), v.cpu(), l0[..., :n, :].cpu())[1]
+        torch.testing.assert_close(cs.float().cpu(), cs_ref.float()[..., :G, :nk], rtol=3e-2, atol=2e-3)

@@ -63,6 +63,8 @@ def build_wan(dev, args, timer):
                                       lambda q, k, v, o_in, indices, counts, o_scale: bench._csp128_work(q, k, v, indices, counts, extra=1))
     ops_pkg.dense_attn = timer.wrap("dense_attn", ops_pkg.dense_attn, bench._dense_work)
     ops_pkg.dense_colsum_attn = timer.wrap("dense_colsum_attn", ops_pkg.dense_colsum_attn, bench._colsum_work)
+    ops_pkg.dense_colsum_topk_mask = timer.wrap("dense_colsum_topk_mask", ops_pkg.dense_colsum_topk_mask,
+                                                lambda q, k, v, p, *a: bench._colsum_work(q, k, v, p))
 
     def mm1_fp8_work(x, fc1w, packed, fc1b, act_T, indices, counts, *a, **k):
         Mr, K = x.shape
