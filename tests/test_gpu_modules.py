@@ -125,3 +125,67 @@ def test_ops_are_hipgraph_capturable():
         assert torch.equal(a, b)
     for a, b in zip(eager_state, graph_state):
         assert torch.equal(a, b)
+
+
+def test_step_cache_and_sparse_attention_over_the_shipped_skip_schedule(fresh_config):
+    """The transformer loop of the reference's HunyuanVideo model (examples/hunyuan/hyvideo/modules/models.py:732-741 skip check,
+    :796-835 block loop + store) on the GPU modules: 60 SparseDiffAttn layers (HIP kernels, tiny sequence) + StepCache over
+    the shipped schedule (full steps {0, 1, 10, 40}; skipped {7, 11, 13, ...}) for inference steps 0..24.
+    * every computed (step, layer) sees exactly the counter coordinates and full-step flag of the reference's odometer
+      (tests/golden/layer_counter.pt, generated from the imported reference);
+    * a skipped step advances the odometer by one model invocation without touching a layer and returns the stored state;
+    * sparse steps on unchanged q, k, v reproduce the dense output (cache + delta) to bf16 precision."""
+    import os
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd.modules import SparseDiffAttn
+    from chipmunk_amd.util import StepCache
+    from chipmunk_amd.util import config as cfgmod
+    from chipmunk_amd.util.layer_counter import LayerCounter
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgmod.load_from_file(os.path.join(root, "configs", "hunyuan_c3.yml"))
+    cfg = fresh_config
+    cfg["steps"] = 50
+    assert cfg["step_caching"]["is_enabled"]
+    skip = cfg["step_caching"]["skip_step_schedule"]
+    gold = torch.load(os.path.join(root, "tests", "golden", "layer_counter.pt"))["hunyuan"]   # rows: (step, layer, sub, inv', full_attn, full_mlp)
+    dev = torch.device("cuda:0")
+    L, H, vid, txt = 60, 2, (4, 6, 16), 64
+    N = vid[0] * vid[1] * vid[2] + txt
+    g = torch.Generator().manual_seed(11)
+    q, k, v = [torch.randn(1, H, N, 128, generator=g).to(torch.bfloat16).to(dev) for _ in range(3)]
+    layers = []
+    for _ in range(L):
+        layer_num, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
+        layers.append(SparseDiffAttn(layer_num, counter))
+    layers[0].initialize_static_mask(vid, txt, H, dev)
+    cache = StepCache(counter)
+    dense = torch.ops.chipmunk.dense_attn(q, k, v)[0]
+    computed, skipped, last_hidden = [], [], None
+    for step in range(25):
+        assert (counter.cur_inference_step, counter.cur_layer, counter.cur_layer_submodule) == (step, 0, 0)
+        if cache.should_skip(step):
+            assert step in skip
+            out = cache.skip()
+            assert torch.equal(out, last_hidden) and out.data_ptr() == stored_ptr, "a skipped step returns the stored state"
+            skipped.append(step)
+            continue
+        assert step not in skip
+        hidden = None
+        for li, layer in enumerate(layers):
+            row = gold[step * L + li]
+            assert (counter.cur_inference_step, counter.cur_layer, counter.cur_layer_submodule) == tuple(int(x) for x in row[:3])
+            assert int(counter.should_do_full_attn_step()) == int(row[4])
+            if step > 0 or li > 0:
+                layer.storage.load_async_wait()
+            layers[(li + 1) % L].storage.load_async()
+            hidden = layer(q, k, v)
+            assert counter.cur_model_invocation_per_step == int(row[3])
+            if li in (0, 1, 2, 31, 59):
+                atol = 2e-2 if li < 2 or row[4] else 6e-2     # dense layers / full steps are the dense kernel; sparse = cache + delta
+                assert (hidden.float() - dense.float()).abs().max().item() < atol, (step, li)
+        cache.store(hidden)
+        last_hidden, stored_ptr = hidden.clone(), cache._cache[0].data_ptr()
+        computed.append(step)
+    torch.cuda.synchronize()
+    assert skipped == sorted(s for s in skip if s < 25) and len(computed) + len(skipped) == 25
+    assert set(computed) >= {0, 1, 10}
