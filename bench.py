@@ -1036,7 +1036,7 @@ def main():
         return
     if hunyuan:
         value = args.steps / elapsed
-        scaling = "strong" if wl.sp else "weak"
+        scaling = "strong"      # the HunyuanVideo job is one fixed sequence at every N (N = 1 included): total work is fixed
         if wl.sp:
             if wl.mode == "heads":
                 desc["parallelism"] = (f"head-parallel x{world} (attention: {wl.lh} heads/rank, all-to-all over RCCL pipelined in head chunks "

@@ -33,7 +33,7 @@ constexpr int LDS_BYTES = QLDS + 2 * 8192;   // 80 KiB: two workgroups per CU = 
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
 // timing ablations (results wrong; read SQ_WAVE_CYCLES, not the clock): 1 = no softmax pipelines, 2 = no V^T reads,
-// 4 = no DMA / vmcnt / barrier, 8 = no K re-reads and no Q window reads
+// 4 = no DMA / vmcnt / barrier, 8 = no K re-reads and no Q window reads, 16 = exp2 -> multiply, 32 = no row sums
 #ifndef A96_ABL
 #define A96_ABL 0
 #endif
@@ -305,11 +305,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             });
         }
         if constexpr (W >= 1 && W <= 16) {
+#if A96_ABL & 16
+            float e = s[QB][W - 1] * 0.5f;   // timing ablation: a full-rate multiply in place of the transcendental
+#else
             float e = __builtin_amdgcn_exp2f(s[QB][W - 1]);
+#endif
             pin(e);
             s[QB][W - 1] = e;
         }
-        if constexpr (W >= 2 && W <= 17) {
+        if constexpr (W >= 2 && W <= 17 && !(A96_ABL & 32)) {
             lacc[QB][W & 1] += s[QB][W - 2];
             pin(lacc[QB][W & 1]);
         }
