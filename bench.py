@@ -313,6 +313,8 @@ class HunyuanBlock:
     12288), [attention], ``linear2`` over cat(attn, gelu(mlp)) (15360 -> 3072) + gated residual.  hipBLASLt GEMMs, torch
     elementwise ops -- model code, not this library; both the sparse loop and the dense comparators run exactly this."""
 
+    _rope = {}
+
     def __init__(self, kind, dev, hid, ffn, heads, projections=True):
         bf = dict(device=dev, dtype=torch.bfloat16)
         self.kind, self.hid, self.ffn, self.heads, self.projections = kind, hid, ffn, heads, projections
@@ -324,6 +326,8 @@ class HunyuanBlock:
             self.lin1, self.lin2 = lin(hid, 3 * hid + ffn), lin(hid + ffn, hid)
         # shift / scale / gate vectors of the block's modulation (the model derives them from the timestep embedding)
         self.mod = [torch.randn(hid, **bf) * 0.02 for _ in range(6)]
+        self.qk_w = [torch.ones(hid // heads, **bf) for _ in range(2)]      # RMSNorm weights of q and k
+
 
     @staticmethod
     def _ln_mod(x, shift, scale):
@@ -332,10 +336,17 @@ class HunyuanBlock:
 
     def _qk_norm(self, h):
         """Projection output -> the attention's operands: split, q / k RMSNorm over the head dimension, head-major layout -- one
-        pass of chipmunk.qkv_split_norm (torch's rearrange + rms_norm x 2 + three transposes cost 8+ ms for these 2.2 GB,
+        pass of chipmunk.qkv_split_norm, rotary embedding of the image rows included (torch's rearrange + rms_norm x 2 + rotary +
+        three transposes cost 8+ ms for these 2.2 GB,
         tools/block_probe.py).  Run for its cost: attention consumes the synthetic q, k, v (see the module docstring)."""
         import chipmunk_amd.ops as ops_pkg
-        ops_pkg.qkv_split_norm(h, None, None, self.heads, 1e-6)
+        rows = max(h.shape[0] - 256, 1)       # rotary tables of the image rows (all but the text rows at the end), shared by all blocks
+        rope = HunyuanBlock._rope.get((rows, h.device))
+        if rope is None:
+            ang = torch.rand(rows, 64, device=h.device) * 6.2831853
+            rope = HunyuanBlock._rope[(rows, h.device)] = (ang.cos().repeat_interleave(2, dim=1).contiguous(),
+                                                           ang.sin().repeat_interleave(2, dim=1).contiguous())
+        ops_pkg.qkv_split_norm(h, self.qk_w[0], self.qk_w[1], self.heads, 1e-6, rope[0], rope[1])
 
     def pre(self, x):
         """Everything in front of the attention; returns what post() needs (single-stream blocks: the MLP half of linear1)."""
@@ -736,7 +747,7 @@ class Hunyuan:
                 "block": ("LayerNorm+modulate, QKV projection, q/k norm, attention, output projection, gated residuals, MLP with tanh-GELU in "
                           "fc1's epilogue (single-stream blocks: the fused linear1 / linear2 weights, computed as two GEMMs each over "
                           "views, no concatenated copy) -- hipBLASLt GEMMs + torch elementwise ops, dense as in the reference "
-                          "(mlp.is_enabled: false); split + q/k RMSNorm + head-major layout by chipmunk.qkv_split_norm; RoPE omitted") if not self.args.no_projections else
+                          "(mlp.is_enabled: false); split + q/k RMSNorm + rotary embedding + head-major layout by chipmunk.qkv_split_norm") if not self.args.no_projections else
                          "dense fc2(gelu_tanh(fc1(x))) per block (two hipBLASLt GEMMs)",
                 "attn_top_keys": self.cfg["attn"]["top_keys"], "step_caching": bool(self.cfg["step_caching"]["is_enabled"]),
                 "caches": "pinned-host offload" if self.args.offload else "resident in HBM (offloading.keep_resident_if_fits)",

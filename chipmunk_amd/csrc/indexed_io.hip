@@ -939,9 +939,13 @@ int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, i
 // three to the [B, H, n, 128] operands the kernels take -- two norm passes and three transposing copies in torch (8+ ms for the
 // 2.2 GB of a HunyuanVideo layer).  Here: one 16-lane group per 256-byte (token, q|k|v, head) segment, 16 bytes per lane, the
 // sum of squares by DPP inside the group; reads are contiguous over the projection's rows, writes are whole 256-byte rows.
+// Optional rotary embedding of q and k (apply_rotary_emb, posemb_layers.py:133-172, the (cos, sin) form): for the first
+// `rope_rows` tokens out = bf16(x_f32 * cos + rotate_half(x_f32) * sin), pairs (2i, 2i+1) -> (-x[2i+1], x[2i]); cos / sin fp32 [rope_rows, 128].
+// A lane holds 8 consecutive elements = 4 whole pairs, so the rotation is lane-local.
 __global__ __launch_bounds__(256) void qkv_split_norm_kernel(const uint16_t *qkv, int64_t row_stride, const uint16_t *qw,
                                                              const uint16_t *kw, uint16_t *q, uint16_t *k, uint16_t *v, int64_t n,
-                                                             int H, float eps, int64_t segments) {
+                                                             int H, float eps, int64_t segments, const float *fcos, const float *fsin,
+                                                             int64_t rope_rows) {
     const int l15 = threadIdx.x & 15;
     u32x4 wq = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, wk = wq;   // bf16 1.0 pairs
     if (qw) wq = *(const u32x4 *)(qw + l15 * 8);
@@ -968,23 +972,36 @@ __global__ __launch_bounds__(256) void qkv_split_norm_kernel(const uint16_t *qkv
                 round_bf16_pair(a, b);                                  // .type_as(x)
                 x[e] = pack_bf16x2(a * __uint_as_float(w[e] << 16), b * __uint_as_float(w[e] & 0xffff0000u));   // * weight, in bf16
             }
+            if (fcos && tok < rope_rows) {
+                const f32x4 c0 = *(const f32x4 *)(fcos + tok * 128 + l15 * 8), c1 = *(const f32x4 *)(fcos + tok * 128 + l15 * 8 + 4);
+                const f32x4 s0 = *(const f32x4 *)(fsin + tok * 128 + l15 * 8), s1 = *(const f32x4 *)(fsin + tok * 128 + l15 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float re = __uint_as_float(x[e] << 16), im = __uint_as_float(x[e] & 0xffff0000u);
+                    const float cr = e < 2 ? c0[2 * e] : c1[2 * e - 4], ci = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
+                    const float sr = e < 2 ? s0[2 * e] : s1[2 * e - 4], si = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+                    x[e] = pack_bf16x2(re * cr + (-im) * sr, im * ci + re * si);
+                }
+            }
         }
         *(u32x4 *)dst = x;
     }
 }
 
 extern "C" int chipmunk_qkv_split_norm(const void *qkv, int64_t row_stride, const void *q_weight, const void *k_weight, void *q,
-                                       void *k, void *v, int64_t n, int heads, float eps, void *stream) {
+                                       void *k, void *v, int64_t n, int heads, float eps, const float *freqs_cos,
+                                       const float *freqs_sin, int64_t rope_rows, void *stream) {
     CM_CHECK(qkv && q && k && v, "qkv_split_norm: null pointer");
     CM_CHECK(n >= 0 && heads > 0 && row_stride >= (int64_t)3 * heads * 128, "qkv_split_norm: bad sizes");
     CM_CHECK((((uintptr_t)qkv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)q_weight | (uintptr_t)k_weight) & 15) == 0 &&
-                 (row_stride & 7) == 0,
+                 (row_stride & 7) == 0 && (((uintptr_t)freqs_cos | (uintptr_t)freqs_sin) & 15) == 0,
              "qkv_split_norm: pointers and the row stride must be 16-byte aligned");
+    CM_CHECK((freqs_cos == nullptr) == (freqs_sin == nullptr) && rope_rows >= 0 && rope_rows <= n, "qkv_split_norm: bad rotary arguments");
     if (n == 0) return CHIPMUNK_OK;
     const int64_t segments = n * 3 * heads, blocks = (segments + 15) / 16;
     hipLaunchKernelGGL(qkv_split_norm_kernel, dim3((unsigned)(blocks > 256 * 64 ? 256 * 64 : blocks)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)qkv, row_stride, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (uint16_t *)q,
-                       (uint16_t *)k, (uint16_t *)v, n, heads, eps, segments);
+                       (uint16_t *)k, (uint16_t *)v, n, heads, eps, segments, freqs_cos, freqs_sin, freqs_cos ? rope_rows : 0);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

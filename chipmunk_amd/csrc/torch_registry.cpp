@@ -559,7 +559,8 @@ at::Tensor bitunpack(at::Tensor packed, at::IntArrayRef shape) {
 
 // [n, >= 3*heads*128] projection output -> q, k, v [1, heads, n, 128] with q/k RMSNorm (see chipmunk_qkv_split_norm)
 std::vector<at::Tensor> qkv_split_norm(at::Tensor qkv, const c10::optional<at::Tensor> &q_weight, const c10::optional<at::Tensor> &k_weight,
-                                       int64_t heads, double eps) {
+                                       int64_t heads, double eps, const c10::optional<at::Tensor> &freqs_cos,
+                                       const c10::optional<at::Tensor> &freqs_sin) {
     CHECK_DEV(qkv); CHECK_BF16(qkv);
     TORCH_CHECK(qkv.dim() == 2 && qkv.stride(1) == 1 && qkv.size(1) >= 3 * heads * 128, "qkv_split_norm: qkv must be [n, >= 3*heads*128] with a contiguous last dim");
     const void *qw = nullptr, *kw = nullptr;
@@ -567,10 +568,21 @@ std::vector<at::Tensor> qkv_split_norm(at::Tensor qkv, const c10::optional<at::T
     if (q_weight.has_value() && q_weight->defined()) { qwc = q_weight->contiguous(); CHECK_DEV(qwc); CHECK_BF16(qwc); TORCH_CHECK(qwc.numel() == 128); qw = qwc.data_ptr(); }
     if (k_weight.has_value() && k_weight->defined()) { kwc = k_weight->contiguous(); CHECK_DEV(kwc); CHECK_BF16(kwc); TORCH_CHECK(kwc.numel() == 128); kw = kwc.data_ptr(); }
     const int64_t n = qkv.size(0);
+    const float *fc = nullptr, *fs = nullptr;
+    int64_t rope_rows = 0;
+    at::Tensor fcc, fsc;
+    if (freqs_cos.has_value() && freqs_cos->defined()) {
+        TORCH_CHECK(freqs_sin.has_value() && freqs_sin->defined(), "qkv_split_norm: freqs_cos without freqs_sin");
+        fcc = freqs_cos->contiguous(), fsc = freqs_sin->contiguous();
+        CHECK_DEV(fcc); CHECK_DEV(fsc);
+        TORCH_CHECK(fcc.scalar_type() == at::kFloat && fsc.scalar_type() == at::kFloat && fcc.dim() == 2 && fcc.size(1) == 128 &&
+                    fsc.sizes() == fcc.sizes() && fcc.size(0) <= n, "qkv_split_norm: freqs must be float32 [rows <= n, 128]");
+        fc = fcc.data_ptr<float>(), fs = fsc.data_ptr<float>(), rope_rows = fcc.size(0);
+    }
     c10::DeviceGuard guard(qkv.device());
     at::Tensor out = at::empty({3, 1, heads, n, 128}, qkv.options());
     check(chipmunk_qkv_split_norm(qkv.data_ptr(), qkv.stride(0), qw, kw, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), n,
-                                  (int)heads, (float)eps, cur_stream(qkv)),
+                                  (int)heads, (float)eps, fc, fs, rope_rows, cur_stream(qkv)),
           "qkv_split_norm");
     return {out[0], out[1], out[2]};
 }
@@ -627,7 +639,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
     m.def("gather_rows(Tensor src, Tensor map) -> Tensor");
-    m.def("qkv_split_norm(Tensor qkv, Tensor? q_weight, Tensor? k_weight, int heads, float eps) -> Tensor[]");
+    m.def("qkv_split_norm(Tensor qkv, Tensor? q_weight, Tensor? k_weight, int heads, float eps, Tensor? freqs_cos=None, Tensor? freqs_sin=None) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {

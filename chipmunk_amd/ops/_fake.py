@@ -66,7 +66,7 @@ def _register():
                 q.new_empty((B, H, Nq, 1), dtype=torch.float32)]
 
     @lib.register_fake("chipmunk::qkv_split_norm")
-    def _(qkv, q_weight, k_weight, heads, eps):
+    def _(qkv, q_weight, k_weight, heads, eps, freqs_cos=None, freqs_sin=None):
         out = qkv.new_empty((3, 1, heads, qkv.shape[0], 128))
         return [out[0], out[1], out[2]]
 

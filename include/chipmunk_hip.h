@@ -221,10 +221,13 @@ int chipmunk_release_scratch(void);
 /* ---------------------------------------------------------------- projection output -> attention operands
  * qkv [n rows of row_stride elements, the first 3*heads*128 of each = (q|k|v, head, 128)] bf16  ->  q, k, v [heads, n, 128] bf16
  * with RMSNorm over the 128 head elements applied to q and k: bf16(bf16(x * rsqrt(mean(x^2) + eps)) * weight); weights bf16
- * [128] or NULL (= ones).  One pass instead of the caller's rearrange + two RMSNorm modules + three transposes
- * (examples/hunyuan/hyvideo/modules/models.py:188-193,376-381; norm_layers.py:43-58). */
+ * [128] or NULL (= ones).  Optionally the rotary embedding of q and k for the first rope_rows tokens (the image tokens;
+ * apply_rotary_emb, posemb_layers.py:133-172, (cos, sin) form): bf16(x * cos + rotate_half(x) * sin) in fp32, freqs_cos /
+ * freqs_sin fp32 [rope_rows, 128] or both NULL.  One pass instead of the caller's rearrange + two RMSNorm modules + rotary
+ * embedding + three transposes (examples/hunyuan/hyvideo/modules/models.py:188-199,376-392; norm_layers.py:43-58). */
 int chipmunk_qkv_split_norm(const void *qkv, int64_t row_stride, const void *q_weight, const void *k_weight, void *q, void *k,
-                            void *v, int64_t n, int heads, float eps, void *stream);
+                            void *v, int64_t n, int heads, float eps, const float *freqs_cos, const float *freqs_sin,
+                            int64_t rope_rows, void *stream);
 
 #ifdef __cplusplus
 }

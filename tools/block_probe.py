@@ -33,7 +33,7 @@ with torch.no_grad():
         g = blk.pre(x)
         print(f"{kind}: pre {t(lambda: blk.pre(x)):.2f} ms, post {t(lambda: blk.post(x, g, o)):.2f} ms")
     hq = torch.randn(N, 3 * HID, device=dev, dtype=torch.bfloat16)
-    print(f"q/k norm stand-in (layer_norm over 128 on [N, 48, 128] view): {t(lambda: blk._qk_norm(hq)):.2f} ms")
+    print(f"qkv_split_norm (split + q/k RMSNorm + rotary + head-major, 2.2 GB): {t(lambda: blk._qk_norm(hq)):.2f} ms")
     w2 = blk.lin2.weight
     a2 = torch.randn(N, HID, device=dev, dtype=torch.bfloat16)
     g2 = torch.randn(N, FFN, device=dev, dtype=torch.bfloat16)
