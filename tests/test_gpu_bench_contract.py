@@ -1,0 +1,69 @@
+"""bench.py's output contract on the GPU box, at reduced layer counts so the three workloads finish in well under a minute
+each: ONE JSON line with the driver's keys, a `roofline` object for the dominant kernel (HIP-event durations from the timed
+region), a `cpu_baseline` object, the measured legs of the HunyuanVideo line, and the sharded code paths at world size 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _bench(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def _check_common(d, steps, warmup):
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d["metric"] == "DiT denoise steps/sec at fixed sparsity" and d["unit"] == "steps/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.02 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["launches_in_timed_region"] > 0 and r["avg_launch_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_hunyuan_line_with_its_legs():
+    d = _bench("--layers", "4", "--steps", "3", "--warmup", "3")
+    _check_common(d, 3, 3)
+    assert d["config"]["workload"].startswith("hunyuan_c3") and d["dtype"] == "bf16" and d["scaling"] == "strong"
+    assert set(d["kernels"]) >= {"dense_attn", "csp_128_attn"}
+    comp = d["dense_gpu_comparator"]
+    assert comp["sparse_over_dense"] > 1.0 and "FLASH" in comp["backend"] and comp["own_dense"]["sparse_over_own_dense"] > 1.0
+    leg = d["step_caching_leg"]
+    assert leg["skipped"] == 6 and leg["kinds"].count("sparse") == 3 and leg["steps_per_s"] > d["value"]
+    assert d["running_max_fallback_leg"]["csp_128_attn_avg_ms"] > 0
+    assert 0.75 < d["sparsity_82_leg"]["column_sparsity"] < 0.86 and 0.90 < d["column_sparsity"] < 0.95
+    assert d["roofline"]["traffic_source"] is None or d["roofline"]["traffic_source"].startswith("profiles/")
+
+
+@pytest.mark.parametrize("mode,chunks", [("heads", "8,16"), ("groups", "6,18")])
+def test_sharded_paths_at_world_size_one(mode, chunks):
+    d = _bench("--workload", "hunyuan_sp", "--sp-mode", mode, "--sp-chunks", chunks, "--layers", "3", "--steps", "2", "--warmup", "3",
+               "--no-cpu-baseline", "--no-legs")
+    assert d["config"]["sp_mode"] == mode and d["config"]["dist_world_size"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert str([int(c) for c in chunks.split(",")]) in d["config"]["parallelism"]
+
+
+def test_wan_and_flux_lines():
+    w = _bench("--workload", "wan_c5", "--layers", "4", "--steps", "3", "--warmup", "12", "--dense-steps", "1")
+    _check_common(w, 3, 12)
+    assert w["config"]["workload"].startswith("wan_c5") and "fp8" in w["dtype"] and "csp_mlp_mm1_fp8" in w["kernels"]
+    assert w["offload"]["modules_offloaded"] >= 1 and w["offload"]["pinned_host_bytes_read_per_sparse_step"] > 0
+    assert w["invocation_kinds_seen"]["sparse"] > 0 and w["dense_gpu_comparator"]["sparse_over_dense"] > 0
+    f = _bench("--workload", "flux_c2", "--layers", "6", "--steps", "6", "--warmup", "12", "--dense-steps", "1")
+    _check_common(f, 6, 12)
+    assert f["config"]["workload"].startswith("flux_c2") and {"csp_attn", "csp_mlp_mm2"} <= set(f["kernels"])
