@@ -542,14 +542,14 @@ class Hunyuan:
             ls = self.n_img // world
             send = torch.empty(world, ls, 1, 1, 3, D, device=dev, dtype=torch.bfloat16)
             recv = torch.empty_like(send)
-            call = lambda: dist.all_to_all_single(recv, send, group=group)
+            call = lambda: dist_mod._all_to_all_single(recv, send, group)
             scale = 1.0 / world                                            # a rank attends the whole sequence of its heads
             t_fn = lambda h: self.t_attn_ms(h)
         else:
             pad = max(dist_mod.group_rows(self.N, world))
             send = torch.empty(2, 1, 1, pad, D, device=dev, dtype=torch.bfloat16)
             recv = torch.empty(world * 2, 1, 1, pad, D, device=dev, dtype=torch.bfloat16)
-            call = lambda: dist.all_gather_into_tensor(recv, send, group=group)
+            call = lambda: dist_mod.all_gather_base(recv, send, group)
             t_fn = lambda h: 0.215 + self.t_attn_ms(h) / world             # 1/world of every head's query groups
         for _ in range(2):
             call()
@@ -740,7 +740,8 @@ class Hunyuan:
     def desc(self):
         blocks = (f"{self.n_double} double-stream + {self.n_layers - self.n_double} single-stream blocks" if not self.args.no_projections
                   else f"{self.n_layers} blocks, attention + MLP only")
-        return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": HunyuanVideo 720x1280x129, {self.n_img} image + "
+        shape = "HunyuanVideo 720x1280x129" if self.vid == (33, 45, 80) else f"HunyuanVideo blocks on a {self.vid[0]}x{self.vid[1]}x{self.vid[2]} patch grid"
+        return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": {shape}, {self.n_img} image + "
                 f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {blocks} (first 2 attention layers dense)",
                 "attention": "SparseDiffAttn, configs/hunyuan_c3.yml (full steps {0,1,10,40}, top 5% + 1% random + text columns, "
                              "bit-packed masks)",
@@ -904,16 +905,32 @@ def main():
             args.gpus = world
         else:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    # stdout carries exactly ONE line (rank 0's JSON): everything libraries print on fd 1 in between -- gloo's connection notes,
+    # hipBLASLt / MIOpen chatter -- goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = real_stdout
     if args.launch_only:
         return launch_only(rank, local_rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    assert torch.cuda.device_count() >= world or world == 1, f"{world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}"
+    # BENCH_SHARE_GPU=1: rehearsal of the multi-rank code paths on ONE device -- every rank uses cuda:0 and the collectives go
+    # through gloo with host staging (RCCL refuses two ranks on one GPU).  Exercises the launcher, the chunk planner, the
+    # pipelines, per-chunk modules and the N > 1 output line; its timings mean nothing and the line says so.
+    share_gpu = world > 1 and os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+    assert torch.cuda.device_count() >= world or world == 1 or share_gpu, \
+        f"{world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.workload == "auto":
         args.workload = "hunyuan_c3" if world == 1 else "hunyuan_sp"
     hunyuan = args.workload.startswith("hunyuan")
@@ -1059,6 +1076,8 @@ def main():
                                        f"all-gather over RCCL pipelined in head chunks {wl.chunks}); projections + MLP on the same rows")
                 desc["bytes_received_per_rank_per_layer"] = wl.pipe.bytes_per_layer_received
             desc["sp_mode"] = wl.mode
+            if share_gpu:
+                desc["rehearsal"] = "BENCH_SHARE_GPU=1: all ranks on one device, collectives staged through host memory over gloo -- NOT a measurement"
             desc["dist_world_size"] = world
             desc["chunk_plan"] = wl.plan_info
             desc["exchange"] = not args.sp_no_exchange

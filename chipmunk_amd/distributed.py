@@ -41,11 +41,28 @@ def get_dist() -> Tuple[object, Optional[int], Optional[int]]:
     return DIST_GROUP, DIST_RANK, DIST_WORLD_SIZE
 
 
+def _staged(group, *tensors) -> bool:
+    """True when the collective has to go through host memory: device tensors on a backend without device collectives (gloo).
+    Only the single-GPU rehearsal of the multi-rank paths takes this route (bench.py BENCH_SHARE_GPU=1: several ranks share one
+    device); on RCCL the tensors go as they are."""
+    return any(t.is_cuda for t in tensors) and dist.get_backend(group) == "gloo"
+
+
+def all_gather_base(out: torch.Tensor, x: torch.Tensor, group) -> None:
+    """``dist.all_gather_into_tensor`` (concatenation form: ``out`` dim 0 = world * ``x`` dim 0)."""
+    if _staged(group, out, x):
+        oc, xc = torch.empty(out.shape, dtype=out.dtype), x.cpu()
+        dist.all_gather_into_tensor(oc, xc, group=group)
+        out.copy_(oc)
+        return
+    dist.all_gather_into_tensor(out, x, group=group)
+
+
 def all_gather_into_tensor(x: torch.Tensor, group) -> torch.Tensor:
     world = dist.get_world_size(group)
     x = x.contiguous()
     out = torch.empty(world * x.size(0), *x.shape[1:], dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x, group=group)
+    all_gather_base(out, x, group)
     return out
 
 
@@ -58,6 +75,11 @@ def all_gather(tensor: torch.Tensor) -> torch.Tensor:
 @torch.compiler.disable()
 def _all_to_all_single(output: torch.Tensor, input: torch.Tensor, group) -> None:
     assert input.is_contiguous() and output.is_contiguous(), "all-to-all buffers must be contiguous"
+    if _staged(group, output, input):
+        oc = torch.empty(output.shape, dtype=output.dtype)
+        dist.all_to_all_single(oc, input.cpu(), group=group)
+        output.copy_(oc)
+        return
     dist.all_to_all_single(output, input, group=group)
 
 
@@ -131,7 +153,7 @@ def head_parallel_attention(attn: Callable, q: torch.Tensor, k: torch.Tensor, v:
     b = q.shape[0]
     ot = ot.reshape(world, b, lh, ot.shape[2], ot.shape[3]).permute(1, 3, 0, 2, 4).reshape(b, ot.shape[2], -1)
     oe = F.scaled_dot_product_attention(qe, ke, ve)
-    oe = oe.permute(0, 2, 1, 3).reshape(b, oe.shape[2], -1)
+    oe = oe.permute(0, 2, 1, 3).reshape(b, oe.shape[2], heads * q.shape[3])     # (may be empty: no padding rows)
     return torch.cat([oi, ot, oe], dim=1).contiguous()
 
 
@@ -430,7 +452,7 @@ class GroupParallelPipeline:
         self.send[c][1, :, :, :r].copy_(v[:, off:off + ch])
         if self.exchange:
             # concatenation form (dim 0 = G * 2): the layout every backend accepts
-            dist.all_gather_into_tensor(self.recv[c].view(-1, *self.recv[c].shape[2:]), self.send[c], group=self.group)
+            all_gather_base(self.recv[c].view(-1, *self.recv[c].shape[2:]), self.send[c], self.group)
         elif self.world == 1:
             self.recv[c][0].copy_(self.send[c])
         lo = 0

@@ -14,8 +14,9 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline", "cpu_baseline"}
 
 
-def _bench(*args, timeout=600):
+def _bench(*args, timeout=600, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -67,3 +68,16 @@ def test_wan_and_flux_lines():
     f = _bench("--workload", "flux_c2", "--layers", "6", "--steps", "6", "--warmup", "12", "--dense-steps", "1")
     _check_common(f, 6, 12)
     assert f["config"]["workload"].startswith("flux_c2") and {"csp_attn", "csp_mlp_mm2"} <= set(f["kernels"])
+
+
+@pytest.mark.parametrize("mode", ["heads", "groups"])
+def test_two_rank_line_rehearsed_on_one_gpu(mode):
+    """`bench.py --gpus 2` end to end on a one-GPU box (BENCH_SHARE_GPU=1: both ranks on cuda:0, gloo with host staging): the
+    launcher, the chunk planner fed by a measured exchange, per-chunk modules with their own slots / query-group offsets, the
+    max-over-ranks timing, the exposed-communication probe and rank 0's single line."""
+    d = _bench("--gpus", "2", "--sp-mode", mode, "--grid", "8,12,16", "--layers", "3", "--steps", "3", "--warmup", "3", BENCH_SHARE_GPU="1")
+    assert d["n_gpus"] == 2 and d["config"]["dist_world_size"] == 2 and d["config"]["sp_mode"] == mode and d["scaling"] == "strong"
+    plan = d["config"]["chunk_plan"]
+    assert sum(plan["chunks"]) == (12 if mode == "heads" else 24) and plan["exchange_ms_per_head_measured"] > 0
+    assert "rehearsal" in d["config"] and d["cpu_baseline"] is None and d["value"] > 0
+    assert 0.0 <= d["exposed_comm"]["exposed_fraction"] <= 1.0
