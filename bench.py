@@ -363,6 +363,16 @@ class HunyuanBlock:
         self._qk_norm(torch.addmm(bias[:3 * hid], xm, w[:3 * hid].t()))
         return torch._addmm_activation(bias[3 * hid:], xm, w[3 * hid:].t(), use_gelu=True)
 
+    def mlp_only(self, x):
+        """Round 2's definition of the block beside the attention: fc2(gelu_tanh(fc1(x))) alone (single-stream blocks: the MLP rows /
+        columns of the fused linear1 / linear2 weights)."""
+        hid = self.hid
+        if self.kind == "double" or not self.projections:
+            return dense_mlp(x, self.fc1, self.fc2)
+        w1, b1, w2 = self.lin1.weight, self.lin1.bias, self.lin2.weight
+        g = torch._addmm_activation(b1[3 * hid:], x, w1[3 * hid:].t(), use_gelu=True)
+        return torch.addmm(self.lin2.bias, g, w2[:, hid:].t())
+
     def _tokens_first(self, o):
         """Attention output -> [rows, hid] token-major (the reference's `b h s d -> b s (h d)`)."""
         if o.dim() == 4:
@@ -522,6 +532,7 @@ class Hunyuan:
         self.static_mask_s = time.perf_counter() - t0
         self.step_events = []
         self.q_scale = 1.0
+        self.mlp_only = False
 
     def _plan_chunks(self, dist_mod, group, heads):
         """Split of the rank's heads into pipeline chunks: explicit (--sp-chunks / --sp-chunk-heads) or from the cost model
@@ -613,6 +624,10 @@ class Hunyuan:
                             a.storage.load_async_wait()
                     for a in self.layers[(li + 1) % L][0]:                 # ... start the next block's load
                         a.storage.load_async()
+                    if self.mlp_only:                      # round 2's step: attention + MLP, nothing else
+                        self._attention(li, attn)
+                        x = blk.mlp_only(self.x)
+                        continue
                     h = blk.pre(x)
                     o = self._attention(li, attn)
                     x = blk.post(x, h, o)
@@ -704,6 +719,20 @@ class Hunyuan:
         timer.records = before
         return {"q_scale": scale, "sparse_step_s": sum(t for _, _, t in times) / len(times),
                 "csp_128_attn_avg_ms": None if summ is None else round(summ["avg_ms"], 4)}
+
+    def round2_definition_leg(self, mean, kinds_timed, sparse_steps=2):
+        """The same sparse steps under round 2's definition of a step (attention + MLP only): what the projections, norms, rotary
+        embedding and residuals added to the block cost, and the timed region's steps/s had they been left out."""
+        self.mlp_only = True
+        times = self.run_steps(12, sparse_steps)
+        self.mlp_only = False
+        s2 = sum(t for _, _, t in times) / len(times)
+        out = {"sparse_step_s": s2, "what": "attention + fc2(gelu(fc1(x))) per block only, as round 2 measured (0.453 steps/s then)"}
+        n = {k: kinds_timed.get(k, 0) for k in ("sparse", "mask", "dense0")}
+        if all(k in mean for k, c in n.items() if c) and sum(n.values()):
+            rest = mean["sparse"] - s2             # the same per step of any kind: every block runs it once
+            out["timed_region_steps_per_s_equivalent"] = sum(n.values()) / sum(c * (s2 if k == "sparse" else mean[k] - rest) for k, c in n.items() if c)
+        return out
 
     def no_exchange_probe(self, sparse_steps=2):
         """N > 1: sparse steps with the collectives switched off (buffers keep stale data: timing only)."""
@@ -1050,6 +1079,8 @@ def main():
             if "sparse" in mean:
                 extra["step_caching_leg"] = wl.step_caching_leg()
                 extra["running_max_fallback_leg"] = wl.qk_scale_leg(args.qk_scale, timer)
+                if not args.no_projections:
+                    extra["round2_step_definition_leg"] = wl.round2_definition_leg(mean, extra["timed_steps"]["kinds"])
             if not args.no_82 and args.top_keys is None:
                 leg = wl.leg_at(0.17)
                 if "schedule_projection_50_steps" in extra:
