@@ -419,10 +419,11 @@ class Hunyuan:
     """HunyuanVideo block loop on `world` ranks (world 1: everything local)."""
 
     # gathered-kernel launch cost at HunyuanVideo size and ~93 % sparsity, ms for `h` heads of the whole sequence
-    # (tools/kbench.py: 1 head 0.91, 3 heads 2.30, 24 heads 12.7): the chunk planner's compute model
+    # (tools/kbench.py, attn96.hip: 1 / 2 / 3 / 4 / 6 heads 0.64 / 1.00 / 1.39 / 1.79 / 2.78 at uniform counts, 24 heads 11.3 in the
+    # bench; a single head's 119 k-key text groups add to the fixed part): the chunk planner's compute model
     @staticmethod
     def t_attn_ms(h):
-        return 0.215 + 0.695 * h if h <= 3 else 0.53 * h
+        return 0.3 + 0.46 * h
 
     def __init__(self, dev, rank, world, args, timer):
         import contextlib

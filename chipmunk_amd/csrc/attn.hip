@@ -754,14 +754,14 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
     // loader wave per 192-row group, ONE workgroup per CU).  Off by default: at equal counts it measured +2.7 % (random
     // keys) / +5.4 % (keys shared between groups) over this file's kernel, but on HunyuanVideo's ragged launches (text /
     // tail groups 13x longer than the rest, one workgroup per CU) 15.5 vs 14.3 ms.
-    // Gathered launches with at least three rounds of long items go to the two-waves-x-96-rows kernel of attn96.hip (same
-    // plan, same scratch): HunyuanVideo 24 heads 12.7 -> 11.1 ms, Wan2.1 (12 heads x 32 760 keys) 1.97 -> 1.67 ms; short items
-    // (FLUX: 21 tiles, 78 vs 130 us) and single heads stay here (its per-item prologue and epilogue are longer).  Option
-    // attn_csp96: 1 = always, 2 = never.
+    // Gathered launches over long key ranges go to the two-waves-x-96-rows kernel of attn96.hip (same plan, same scratch):
+    // HunyuanVideo 24 heads 12.7 -> 11.1 ms, a head-parallel rank's 1 / 2 / 3 heads 0.71 / 1.12 / 1.81 -> 0.64 / 1.00 / 1.39 ms,
+    // Wan2.1 (12 heads x 32 760 keys) 1.97 -> 1.67 ms; short items (FLUX: 21 tiles, 78 vs 130 us: its per-item prologue and
+    // epilogue are longer) stay here.  Option attn_csp96: 1 = always, 2 = never.
     const int o96 = chipmunk_get_option("attn_csp96");
     const bool fits96 = GATHER && !CSONLY && !WRITE_L && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24) &&
                         (p.idx_stride & 3) == 0;   // (its index rows are read 16 bytes at a time)
-    const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 6 * (int64_t)device_cu_count() && p.Nk >= 16384));
+    const bool want96 = fits96 && (o96 == 1 || (o96 == 0 && nblocks >= 128 && p.Nk >= 16384));
     const int o64 = chipmunk_get_option("attn_csp64");
     const bool want64 = GATHER && !CSONLY && !WRITE_L && o64 == 1 && p.Nk < (1 << 24) && p.ks[2] * 2 < (1 << 24) && p.vs[2] * 2 < (1 << 24);
     CM_CHECK((int64_t)p.Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)p.Nk * p.vs[2] * 2 < (1ll << 32),
