@@ -821,10 +821,11 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
     CM_CHECK(a && b && c && bias && pa_cache && scale_a && scale_b, "csp_mlp_mm1_fp8: null tensor pointer");
     if (int e = check_mlp_common(M, F, indices, counts)) return e;
     CM_CHECK(K > 0 && K % 128 == 0, "csp_mlp_mm1_fp8: K must be a positive multiple of 128 (got %d)", K);
+    CM_CHECK(update_cache >= 0 && update_cache <= 2, "csp_mlp_mm1_fp8: update_cache must be 0, 1 or 2");
     CM_CHECK((int64_t)F * K < (1ll << 31) && (int64_t)M * K < (1ll << 31) && (int64_t)F * M < (1ll << 31),
              "csp_mlp_mm1_fp8: operand too large for 32-bit offsets");
     // same tile machinery as the bf16 kernel (buffer-form DMA, tail split, staged epilogue); a k step is 128 fp8 values
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
-                   indices, counts, M, K, F, 0, 0, 0, 0, update_cache ? 2 : 0, scale_a, scale_b};
+                   indices, counts, M, K, F, 0, 0, 0, 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
     return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }

@@ -211,9 +211,9 @@ void csp_mlp_mm1_scatter(at::Tensor a, at::Tensor b_colmajor, at::Tensor c, at::
 }
 
 // native counterpart of the reference's Triton csp_mlp_mm1_fp8 (src/chipmunk/triton/csp_mlp_mm1.py:143-164)
-void csp_mlp_mm1_fp8(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
-                     at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b,
-                     bool update_cache) {
+static void mm1_fp8_impl(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
+                         at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b,
+                         int update_cache) {
     CHECK_DEV(a); CHECK_DEV(b); CHECK_DEV(c); CHECK_DEV(bias); CHECK_DEV(pa_cache_colmajor);
     CHECK_DEV(indices); CHECK_DEV(indices_counts); CHECK_DEV(scale_a); CHECK_DEV(scale_b);
     TORCH_CHECK(a.scalar_type() == at::kFloat8_e4m3fn && b.scalar_type() == at::kFloat8_e4m3fn,
@@ -232,8 +232,19 @@ void csp_mlp_mm1_fp8(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, 
     check(chipmunk_csp_mlp_mm1_fp8(a.data_ptr(), b.data_ptr(), c.data_ptr(), bias.data_ptr(),
                                    pa_cache_colmajor.data_ptr(), indices.data_ptr<int>(),
                                    indices_counts.data_ptr<int>(), scale_a.data_ptr<float>(), scale_b.data_ptr<float>(),
-                                   (int)M, (int)K, (int)F, update_cache ? 1 : 0, cur_stream(a)),
+                                   (int)M, (int)K, (int)F, update_cache, cur_stream(a)),
           "csp_mlp_mm1_fp8");
+}
+
+void csp_mlp_mm1_fp8(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
+                     at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b,
+                     bool update_cache) {
+    mm1_fp8_impl(a, b, c, bias, pa_cache_colmajor, indices, indices_counts, scale_a, scale_b, update_cache ? 1 : 0);
+}
+// fp8 GEMM1 that applies the scatter-add of its own deltas to the cache (the fp8 counterpart of csp_mlp_mm1_scatter)
+void csp_mlp_mm1_fp8_scatter(at::Tensor a, at::Tensor b, at::Tensor c, at::Tensor bias, at::Tensor pa_cache_colmajor,
+                             at::Tensor indices, at::Tensor indices_counts, at::Tensor scale_a, at::Tensor scale_b) {
+    mm1_fp8_impl(a, b, c, bias, pa_cache_colmajor, indices, indices_counts, scale_a, scale_b, 2);
 }
 
 void check_scatter_args(const at::Tensor &packed, const at::Tensor &unpacked, const at::Tensor &inds,
@@ -630,6 +641,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("csp_mlp_mm1_scatter(Tensor a, Tensor b_colmajor, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts) -> ()");
     m.def("csp_mlp_mm2(Tensor mma_a, Tensor mma_b, Tensor indices, Tensor counts, Tensor(mma_c!) mma_c) -> ()");
     m.def("csp_mlp_mm1_fp8(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b, bool update_cache) -> ()");
+    m.def("csp_mlp_mm1_fp8_scatter(Tensor a, Tensor b, Tensor(c!) c, Tensor bias, Tensor(pa_cache_colmajor!) pa_cache_colmajor, Tensor indices, Tensor indices_counts, Tensor scale_a, Tensor scale_b) -> ()");
     m.def("topk_delta_indices(Tensor activation, Tensor(cache!) cache, Tensor(indices!) indices, Tensor(counts!) counts, float sparsity_amount, int multiple_of, float random_amount) -> ()");
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("mask_to_sorted_indices(Tensor mask, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
@@ -644,6 +656,7 @@ TORCH_LIBRARY(chipmunk, m) {
 
 TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("qkv_split_norm", &qkv_split_norm);
+    m.impl("csp_mlp_mm1_fp8_scatter", &csp_mlp_mm1_fp8_scatter);
     m.impl("dense_colsum_topk_mask", &dense_colsum_topk_mask);
     m.impl("csp_mlp_mm1", &csp_mlp_mm1);
     m.impl("csp_mlp_mm2_and_scatter_add", &csp_mlp_mm2_and_scatter_add);

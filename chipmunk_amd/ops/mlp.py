@@ -43,6 +43,16 @@ def mm1_scatter(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Te
     torch.ops.chipmunk.csp_mlp_mm1_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
 
 
+def mm1_fp8_scatter(x: torch.Tensor, fc1w: torch.Tensor, sparse_act_packed: torch.Tensor, fc1b: torch.Tensor,
+                    sparse_act_T: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, scale_a: torch.Tensor,
+                    scale_b: torch.Tensor) -> None:
+    """fp8 GEMM1 + ``csp_scatter_add`` of its output into ``sparse_act_T`` in one kernel (the fp8 counterpart of ``mm1_scatter``;
+    bit-identical in the packed deltas and in the cache to ``csp_mlp_mm1_fp8`` followed by the scatter-add)."""
+    assert x.dtype == torch.float8_e4m3fn and fc1w.dtype == torch.float8_e4m3fn
+    torch.ops.chipmunk.csp_mlp_mm1_fp8_scatter(x, fc1w.contiguous(), sparse_act_packed, fc1b, sparse_act_T, indices, counts,
+                                               scale_a.reshape(1).float(), scale_b.reshape(1).float())
+
+
 FP8_MM1_UPDATES_CACHE = False
 
 
@@ -103,6 +113,11 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
         mm1_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts)
         csp_mlp_mm2(sparse_act_packed, fc2w_T, indices, counts, cached_out)
         return
+    if (x.is_cuda and fc1w.dtype == torch.float8_e4m3fn and x.dtype == torch.float8_e4m3fn and amd_key("mlp", "fused_scatter")
+            and not FP8_MM1_UPDATES_CACHE and x.shape[1] % 128 == 0):
+        mm1_fp8_scatter(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts, mm1_scale_a, mm1_scale_b)
+        csp_mlp_mm2(sparse_act_packed, fc2w_T, indices, counts, cached_out)
+        return
     mm1(x, fc1w, sparse_act_packed, fc1b, sparse_act_T, indices, counts, mm1_scale_a, mm1_scale_b)
     if USE_FUSED_MLP_MATMUL_2:
         mm2_fused(sparse_act_packed, sparse_act_T, indices, counts, sparse_act_packed, fc2w_T, cached_out,
@@ -111,4 +126,4 @@ def run_e2e(x: torch.Tensor, fc1w: torch.Tensor, fc1b: torch.Tensor, fc2w_T: tor
         mm2_unfused(sparse_act_packed, fc2w_T, cached_out, sparse_act_T, indices, counts, num_sms_scatter_add)
 
 
-__all__ = ["mm1", "mm1_scatter", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2", "csp_mlp_mm1_fp8"]
+__all__ = ["mm1", "mm1_scatter", "mm1_fp8_scatter", "mm2_fused", "mm2_unfused", "run_e2e", "csp_mlp_mm2", "csp_mlp_mm1_fp8"]

@@ -113,7 +113,9 @@ int chipmunk_csp_mlp_mm1_scatter(const void *a, const void *b, void *c, const vo
  * fp32 each (the reference passes 0-dim tensors holding the RECIPROCAL quantisation scales, modules/mlp.py:98-99):
  *   x = bf16(gelu_tanh(a.b[idx] * scale_a * scale_b + bias[idx]));  c[m,j] = bf16(x - pa_cache[idx, m])
  * update_cache = 1 additionally stores x into pa_cache like the Triton kernel (:140); 0 leaves the cache to the
- * scatter-add (the bf16 path's contract).  Requires K % 128 == 0. */
+ * scatter-add (the bf16 path's contract); 2 applies that scatter-add itself -- pa_cache[idx, m] += c[m, j] in bf16, bit for
+ * bit what chipmunk_csp_scatter_add would do afterwards (as chipmunk_csp_mlp_mm1_scatter on the bf16 path).
+ * Requires K % 128 == 0. */
 int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, const void *bias, void *pa_cache,
                              const int32_t *indices, const int32_t *counts, const float *scale_a,
                              const float *scale_b, int M, int K, int F, int update_cache, void *stream);

@@ -218,3 +218,28 @@ def test_sparse_mlp_module_fp8_path(dev, fresh_config):
         ref1 = fc2(act(fc1(x1)))
     assert out0.shape == (1, M, K)
     assert_close_bf16(out1, ref1, atol=8e-2, rtol=5e-2, what="fp8 sparse step vs dense fp8 MLP")
+
+
+@pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 128, 768, [0, 768, 256]), (512, 1536, 1024, [512, 256, 1024, 768])])
+def test_fp8_mm1_scatter_equals_fp8_mm1_then_scatter_add(dev, M, K, F, counts):
+    """csp_mlp_mm1_fp8_scatter == csp_mlp_mm1_fp8 (update_cache off) followed by csp_scatter_add: bit for bit in the packed deltas
+    AND in the activation cache (the fp8 counterpart of the bf16 fusion test above)."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(F, K, generator=g) * 0.06
+    sa, sb = 448.0 / x.abs().max(), 448.0 / w.abs().max()
+    a8, b8 = (x * sa).to(torch.float8_e4m3fn).to(dev), (w * sb).to(torch.float8_e4m3fn).to(dev)
+    ra, rb = (1.0 / sa).reshape(1).float().to(dev), (1.0 / sb).reshape(1).float().to(dev)
+    bias = (torch.randn(F, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    cache0 = torch.randn(F, M, generator=g).to(torch.bfloat16).to(dev)
+    inds = torch.stack([torch.randperm(F, generator=g) for _ in range(M // 128)]).to(torch.int32).to(dev)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+    c_a, cache_a = torch.full((M, F), 3.0, dtype=torch.bfloat16, device=dev), cache0.clone()
+    torch.ops.chipmunk.csp_mlp_mm1_fp8(a8, b8, c_a, bias, cache_a, inds, cnt, ra, rb, False)
+    torch.ops.chipmunk.csp_scatter_add(c_a.unsqueeze(0), cache_a.unsqueeze(0), inds.unsqueeze(0), cnt.unsqueeze(0), 6)
+    c_b, cache_b = torch.full((M, F), 3.0, dtype=torch.bfloat16, device=dev), cache0.clone()
+    torch.ops.chipmunk.csp_mlp_mm1_fp8_scatter(a8, b8, c_b, bias, cache_b, inds, cnt, ra, rb)
+    torch.cuda.synchronize()
+    assert torch.equal(c_a, c_b), "packed deltas"
+    assert torch.equal(cache_a, cache_b), "activation cache"
+    assert not torch.equal(cache_b, cache0) or sum(counts) == 0

@@ -263,6 +263,8 @@ def main():
             bench_mlp(w, variants)
         elif w == "fp8_wan":
             bench_fp8_wan()
+        elif w == "mm2_wan":          # GEMM2 at the Wan2.1 1.3B shape (configs[4]): M = 32 768 rows, N2 = 1 536, F = 8 960, 30 % kept
+            bench_mlp("mm2", variants, M=32768, K=1536, F=8960, keep=2816)
         elif w in ("topk", "topkd", "m2i", "copy"):
             bench_io(w)
         else:

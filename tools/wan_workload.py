@@ -74,6 +74,7 @@ def build_wan(dev, args, timer):
             return 2.0 * 128 * K * c, Mr * K + c * K + c * 256 * 2 + c * 6     # fp8 A + gathered fp8 B rows + cache + C + bias/idx
         return work
     mlp_ops.mm1 = timer.wrap("csp_mlp_mm1_fp8", mlp_ops.mm1, mm1_fp8_work)
+    mlp_ops.mm1_fp8_scatter = timer.wrap("csp_mlp_mm1_fp8", mlp_ops.mm1_fp8_scatter, mm1_fp8_work)   # shipped: + the scatter-add
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, bench._mm2_work)
     mlp_ops.csp_mlp_mm2 = timer.wrap("csp_mlp_mm2", mlp_ops.csp_mlp_mm2, bench._mm2_only_work)
 
