@@ -30,7 +30,7 @@ def _newer(target: str, deps) -> bool:
 
 def build_hip_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn64_regs.h"), os.path.join(CSRC, "attn_params.h"), os.path.join(CSRC, "attn64_util.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn64_regs.h"), os.path.join(CSRC, "attn_params.h"), os.path.join(CSRC, "attn64_util.h"), os.path.join(CSRC, "attn96_sched.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
     if force or _newer(HIP_LIB, deps):
         os.makedirs(LIBDIR, exist_ok=True)
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs
