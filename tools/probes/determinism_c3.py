@@ -6,7 +6,7 @@ import torch
 import chipmunk_amd
 from chipmunk_amd import _native
 dev = torch.device("cuda:0")
-N, H, count = 119056, 6, 9088
+N, H, count = 119056, int(os.environ.get('DET_HEADS', '6')), 9088
 G = (N + 191) // 192
 g = torch.Generator(device=dev).manual_seed(3)
 q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
@@ -34,3 +34,11 @@ rep("csp_128_attn, attn96", lambda: (torch.ops.chipmunk.csp_128_attn(q, k, v, in
 rep("csp_128_attn, general kernel", lambda: (torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts),), attn_csp96=2)
 _, l = torch.ops.chipmunk.dense_attn(q, k, v)
 rep("dense_colsum_attn, one pass", lambda: torch.ops.chipmunk.dense_colsum_attn(q, k, v, l))
+rep("csp_128_attn, attn96, running-maximum loop", lambda: (torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts),), n=6, attn_nomax=2)
+rep("csp_128_attn, attn96 (soak)", lambda: (torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts),), n=int(os.environ.get("DET_SOAK", "8")))
+from chipmunk_amd import ops
+st = (torch.rand(1, H, G, N, device=dev, generator=g) < 0.002)
+gr = torch.ones(1, H, G, 1, dtype=torch.bool, device=dev)
+rep("dense_colsum_topk_mask (no cs)", lambda: ops.dense_colsum_topk_mask(q, k, v, l, 5888, 0.0, gr, st), n=3)
+qk = torch.randn(N, 3 * H * 128, device=dev, dtype=torch.bfloat16, generator=g)
+rep("qkv_split_norm", lambda: tuple(ops.qkv_split_norm(qk, None, None, H)), n=3)
