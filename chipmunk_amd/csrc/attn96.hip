@@ -42,7 +42,9 @@ constexpr float MAX_LAG = 4.0f;
 template <int QB, int DB>
 __device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &pf) {
     constexpr int oa = (QB * 4 + DB) * 16;
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(oa), "i"(oa + 15));
+    // (the leading s_nop: the compiler may assemble `vf` with v_mov copies right in front of this statement and cannot know that the
+    //  string is an MFMA, so it adds no wait states between a VALU write and the matrix core's read of that register)
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(oa), "i"(oa + 15));
 }
 template <int KS, int SLOT>
 __device__ __forceinline__ void lds_k(uint32_t addr) {
@@ -343,10 +345,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int vl_cur = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist
         float mxa, mxb, mxc;   // block maxima: this tile's block 0, this tile's block 1, the previous tile's block 2
         __builtin_amdgcn_sched_barrier(0);
+#ifdef A96_FORCE_MAJOR
+        using S = a96s::Major;
+#else
         using S = std::conditional_t<NOMAX, a96s::Pair, a96s::Major>;   // slot tables (tools/gen_attn96_sched.py)
+#endif
         static_for<0, 48>([&](auto sg) {
             constexpr int SG = decltype(sg)::value;
             // LDS reads return in order: a wait states how many of the youngest may still be in flight
+#ifdef A96_TAILWAIT0
+            if constexpr (SG == 1 || SG == 3 || SG == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else
+#endif
+#ifdef A96_ALLWAIT0
+            if constexpr ((SG & 1) == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else
+#endif
             if constexpr (S::WAIT[SG] >= 0 && !(A96_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(S::WAIT[SG]) : "memory");
             if constexpr ((SG & 1) == 0) {   // ---- QK^T
                 constexpr int qb = SG / 16, ks = (SG % 16) / 2, ka = 192 + ks * 4, qa = 224 + ks * 4;
@@ -421,7 +435,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (nomax) {
         for (int tb = 0;; tb += 4) {
             tile(ic<0>{}, ic<1>{}, tb);
-            if (tb >= T4) break;
+            if (tb >= T4) {
+                // the last iteration's V^T fragment reads are still in flight and are consumed after the loop: wait HERE, inside the
+                // loop's last block.  The compiler resolves the values leaving the two loops with register copies on the exit edge,
+                // and a copy of a register whose ds_read has not landed copies the OLD content (seen: 1 launch in ~15 at 24 heads
+                // differing in one 32x32 block of one item -- tools/probes/race96.py; found by the determinism probe at 24 heads)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                break;
+            }
             tile(ic<1>{}, ic<1>{}, tb + 1);
             tile(ic<2>{}, ic<1>{}, tb + 2);
             tile(ic<3>{}, ic<1>{}, tb + 3);
@@ -429,7 +450,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
         for (int tb = 0;; tb += 4) {
             tile(ic<0>{}, ic<0>{}, tb);
-            if (tb >= T4) break;
+            if (tb >= T4) {
+                // the last iteration's V^T fragment reads are still in flight and are consumed after the loop: wait HERE, inside the
+                // loop's last block.  The compiler resolves the values leaving the two loops with register copies on the exit edge,
+                // and a copy of a register whose ds_read has not landed copies the OLD content (seen: 1 launch in ~15 at 24 heads
+                // differing in one 32x32 block of one item -- tools/probes/race96.py; found by the determinism probe at 24 heads)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                break;
+            }
             tile(ic<1>{}, ic<0>{}, tb + 1);
             tile(ic<2>{}, ic<0>{}, tb + 2);
             tile(ic<3>{}, ic<0>{}, tb + 3);

@@ -54,6 +54,24 @@ def test_named_accumulator_kernels_have_no_spills_and_no_compiler_accvgpr(tmp_pa
         elif "v_accvgpr" in line and not inasm and func and any(k in func for k in kernels):
             bad.append((func, line.strip()))
     assert not bad, f"compiler-generated accumulator moves: {bad[:4]} ... ({len(bad)} in all)"
+    # ---- no instruction touches a register whose (asynchronous, inline-asm) LDS read has not been waited for: the compiler takes
+    #      an asm output as defined AT the asm and may copy it -- phi resolution on a loop exit, tuple assembly -- before the
+    #      source's own s_waitcnt (round 3: exactly that on the exit edge of attn96's loops, one launch in ~15 slightly wrong);
+    #      path-sensitive over the kernel's CFG, LDS reads retire in order (tools/audit_async_lds.py); this also checks every
+    #      hand-counted lgkmcnt of the kernels
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_async_lds", os.path.join(ROOT, "tools", "audit_async_lds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\S*:", l)] + [len(lines)]
+    audited = 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        if any(k in lines[a] for k in kernels):
+            hits = mod.audit(lines, a, b)
+            assert not hits, f"{lines[a].split(':')[0]}: registers used while their LDS read is in flight: {hits[:4]}"
+            audited += 1
+    assert audited >= len(kernels)
 
 
 def test_attn96_slot_tables_are_current(tmp_path):
