@@ -133,3 +133,24 @@ def test_c3_running_maximum_loop_vs_oracle(dev, bench_launch, how):
         rows = slice(gi * 192, min((gi + 1) * 192, N))
         ref = oracle.csp_128_attn(q[:, :, rows].cpu(), kc, vc, inds[:, :, gi:gi + 1].cpu().contiguous(), counts[:, :, gi:gi + 1].cpu().contiguous())
         assert_close_bf16(o[:, :, rows], ref, what=f"running-maximum loop ({how}), group {gi}")
+
+
+def test_bench_launch_is_run_to_run_identical(dev, bench_launch):
+    """32 launches of the bench's 24-head gathered launch, both output forms and the running-maximum loop: bit-identical every
+    time.  (No float atomics, slices merged in slice order -- and, since round 3, no register copied while its LDS read is in
+    flight: one launch in ~15 used to differ in one 32x32 block of one item; tools/probes/race96.py, tools/audit_async_lds.py.)"""
+    from chipmunk_amd import _native
+    L = bench_launch
+    ref = torch.ops.chipmunk.csp_128_attn(L["q"], L["k"], L["v"], L["inds"], L["counts"])
+    ref_out = torch.ops.chipmunk.csp_attn_out(L["q"], L["k"], L["v"], L["cache"], L["inds"], L["counts"], 1)
+    for i in range(32):
+        assert torch.equal(torch.ops.chipmunk.csp_128_attn(L["q"], L["k"], L["v"], L["inds"], L["counts"]), ref), f"launch {i}"
+    for i in range(8):
+        assert torch.equal(torch.ops.chipmunk.csp_attn_out(L["q"], L["k"], L["v"], L["cache"], L["inds"], L["counts"], 1), ref_out), f"out form, launch {i}"
+    _native.set_option("attn_nomax", 2)
+    try:
+        ref_rm = torch.ops.chipmunk.csp_128_attn(L["q"], L["k"], L["v"], L["inds"], L["counts"])
+        for i in range(8):
+            assert torch.equal(torch.ops.chipmunk.csp_128_attn(L["q"], L["k"], L["v"], L["inds"], L["counts"]), ref_rm), f"running maximum, launch {i}"
+    finally:
+        _native.set_option("attn_nomax", 0)
