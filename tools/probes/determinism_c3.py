@@ -17,6 +17,7 @@ for h in range(H):
         inds[0, h, g0:g0 + r.shape[0]] = r.topk(count, dim=-1).indices.sort(-1).values.to(torch.int32)
 counts = torch.full((1, H, G), count, dtype=torch.int32, device=dev)
 def rep(name, fn, n=4, **opts):
+    n = max(n, int(os.environ.get('DET_N', '0')))
     for o, val in opts.items():
         _native.set_option(o, val)
     try:
