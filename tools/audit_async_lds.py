@@ -93,6 +93,14 @@ def audit(lines, start, end, max_states=200000):
                 continue
             if op.startswith('s_'):
                 continue
+            if op.startswith('ds_'):                  # LDS writes / atomics without a return value: they count, they define nothing
+                used = regs_of(t[len(op):])
+                for p in pending:
+                    if p[1] & used:
+                        bad.setdefault(i, (t, p[0]))
+                pending.append((i, frozenset()))
+                pending = pending[-15:]
+                continue
             used = regs_of(t)
             for p in pending:
                 if p[1] & used:
