@@ -5,7 +5,7 @@ import torch
 import chipmunk_amd
 from chipmunk_amd import _native
 dev = torch.device("cuda:0")
-N, H, count = 119056, int(os.environ.get("DET_HEADS", "24")), 9088
+N, H, count = int(os.environ.get("DET_N_TOKENS", "119056")), int(os.environ.get("DET_HEADS", "24")), int(os.environ.get("DET_COUNT", "9088"))
 G = (N + 191) // 192
 g = torch.Generator(device=dev).manual_seed(3)
 q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
