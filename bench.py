@@ -297,7 +297,7 @@ def _dense_work(q, k, v, *a):
     return work
 
 
-def _colsum_work(q, k, v, p):
+def _colsum_work(q, k, v, p, *a):
     B, H, Nq, D = q.shape
     Nk = k.shape[2]
     def work():  # one QK^T + PV pass (the column sums are reductions of the same probabilities): Q, O, K, V once + cs written
@@ -394,7 +394,7 @@ class HunyuanBlock:
         # linear2 over cat(attn, gelu(mlp)) (reference :430) = attn @ W[:, :hid]^T + gelu(mlp) @ W[:, hid:]^T: no concatenated copy
         w = self.lin2.weight
         y = torch.addmm(self.lin2.bias, attn_flat, w[:, :hid].t())
-        y = torch.addmm(y, g, w[:, hid:].t())
+        y.addmm_(g, w[:, hid:].t())                 # in place: the out-of-place form first copies y (0.26 ms)
         return torch.addcmul(x, self.mod[2], y)
 
 
@@ -456,12 +456,17 @@ class Hunyuan:
         # the shipped (fused_residual) form of the same kernel: cache +/- sparse attention written to a new tensor
         ops_pkg.csp_attn_out = timer.wrap("csp_128_attn", ops_pkg.csp_attn_out,
                                           lambda q, k, v, o_in, indices, counts, o_scale: _csp128_work(q, k, v, indices, counts, extra=1))
+        # ... and the same kernel over the kept ragged index rows (attn.keep_unpacked_indices)
+        ops_pkg.csp_attn_out_ragged = timer.wrap("csp_128_attn", ops_pkg.csp_attn_out_ragged,
+                                                 lambda q, k, v, o_in, flat, offsets, counts, o_scale: _csp128_work(q, k, v, None, counts, extra=1))
         ops_pkg.dense_attn = timer.wrap("dense_attn", ops_pkg.dense_attn, _dense_work)
         ops_pkg.dense_colsum_attn = timer.wrap("dense_colsum_attn", ops_pkg.dense_colsum_attn, _colsum_work)
         # the shipped mask step: the same pass + the top-k mask kernel reading its partial sums (no column-sum tensor)
         ops_pkg.dense_colsum_topk_mask = timer.wrap("dense_colsum_topk_mask", ops_pkg.dense_colsum_topk_mask,
                                                     lambda q, k, v, p, *a: _colsum_work(q, k, v, p))
         self.ops = ops_pkg
+        from chipmunk_amd.util.config import amd_key
+        self.token_major = bool(amd_key("attn", "token_major_output"))    # the own-dense comparator gets the same output layout
 
         self.vid = tuple(int(x) for x in args.grid.split(","))
         self.txt = 256
@@ -601,7 +606,7 @@ class Hunyuan:
         elif how == "sdpa":
             o = flash_sdpa(q, k, v)
         else:                                                      # "own": this library's dense kernel
-            o = self.ops.dense_attn(q, k, v)[0]
+            o = self.ops.dense_attn(q, k, v, self.token_major)[0]
         return o                                                   # [1, H, N, D]: the block does the head -> token transpose
 
     # -- one denoise step: the reference's transformer loop (models.py:732-835) ---------------------------------

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         if (sp >= nsp) return;
     }
     const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
-    const int32_t *idx = GATHER ? p.indices + ((int64_t)bh * p.G + g) * p.idx_stride : nullptr;
+    const IndexRow irow = GATHER ? index_row(p, (int64_t)bh * p.G + g) : IndexRow{nullptr, 0};
+    const int32_t *idx = irow.ptr;
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
     const int row0 = g * QG + w * QW;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         if constexpr (GATHER) {
             if (w == 0) {
                 int pos = T * KVT + lane;
-                pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
+                pos = pos < irow.width ? pos : irow.width - 1;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T & (KRING - 1)) * 64), 4, 0, 0);
             }
         }
@@ -912,6 +913,31 @@ extern "C" int chipmunk_csp_attn_out(const void *q, const void *k, const void *v
     return launch_attn<true, true, false>(p, (hipStream_t)stream);
 }
 
+// chipmunk_csp_attn_out over ragged index rows: row (b, h, g) = indices + idx_offsets[(b*H + h)*G + g], as wide as the distance
+// to the next offset (B*H*G + 1 offsets, multiples of 4); what chipmunk_compact_indices lays out
+extern "C" int chipmunk_csp_attn_out_ragged(const void *q, const void *k, const void *v, const void *o_in, void *o_out,
+                                            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                                            const int64_t o_strides[3], const int32_t *indices, const int64_t *idx_offsets,
+                                            const int32_t *counts, int B, int H, int Nq, int Nk, int o_scale, void *stream) {
+    if (int e = check_common(q, k, v, o_out, B, H, Nq, Nk)) return e;
+    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 7) == 0, "csp_attn_out_ragged: o_in missing or not 8-byte aligned");
+    CM_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
+    CM_CHECK(indices && counts && idx_offsets, "csp_attn_out_ragged: indices / offsets / counts missing");
+    CM_CHECK(((uintptr_t)indices & 15) == 0, "csp_attn_out_ragged: indices must be 16-byte aligned");
+    if (int e = check_strides(q_strides, "q")) return e;
+    if (int e = check_strides(k_strides, "k")) return e;
+    if (int e = check_strides(v_strides, "v")) return e;
+    if (int e = check_strides(o_strides, "o")) return e;
+    AttnParams p = {};
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o_out;
+    p.o_in = (const uint16_t *)o_in;
+    for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i], p.os[i] = o_strides[i];
+    p.indices = indices, p.counts = counts, p.idx_off = idx_offsets;
+    p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG, p.idx_stride = 0;
+    p.o_scale = (float)o_scale;
+    return launch_attn<true, true, false>(p, (hipStream_t)stream);
+}
+
 extern "C" int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,
                                      const int32_t *counts, int B, int H, int Nq, int Nk, int idx_stride,
                                      void *stream) {
@@ -927,9 +953,20 @@ extern "C" int chipmunk_csp_128_attn(const void *q, const void *k, const void *v
     return launch_attn<true, false, false>(p, (hipStream_t)stream);
 }
 
-extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
-                                   const int64_t k_strides[3], const int64_t v_strides[3], void *o, float *l, int B,
-                                   int H, int Nq, int Nk, void *stream) {
+// o_strides == nullptr: contiguous [B, H, Nq, 128]; else (batch, head, row) element strides of `o` (rows of 128 contiguous
+// elements), e.g. token-major [B, Nq, H, 128] storage = {Nq*H*128, 128, H*128}
+static int output_strides(int64_t os[3], const int64_t *o_strides, int H, int Nq) {
+    if (!o_strides) {
+        contiguous_strides(os, H, Nq);
+        return CHIPMUNK_OK;
+    }
+    for (int i = 0; i < 3; ++i) os[i] = o_strides[i];
+    return check_strides(o_strides, "o");
+}
+
+extern "C" int chipmunk_dense_attn_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                           const int64_t k_strides[3], const int64_t v_strides[3], void *o,
+                                           const int64_t *o_strides, float *l, int B, int H, int Nq, int Nk, void *stream) {
     if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
     CM_CHECK(l != nullptr, "dense_attn: l output missing");
     if (int e = check_strides(q_strides, "q")) return e;
@@ -938,7 +975,7 @@ extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, 
     AttnParams p = {};
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
     for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
-    contiguous_strides(p.os, H, Nq);
+    if (int e = output_strides(p.os, o_strides, H, Nq)) return e;
     p.l_out = l;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
@@ -950,10 +987,16 @@ extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, 
     return launch_attn<false, false, true>(p, (hipStream_t)stream);
 }
 
-extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
-                                          const int64_t k_strides[3], const int64_t v_strides[3], const float *pin,
-                                          void *o, void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride,
-                                          void *stream) {
+extern "C" int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                   const int64_t k_strides[3], const int64_t v_strides[3], void *o, float *l, int B,
+                                   int H, int Nq, int Nk, void *stream) {
+    return chipmunk_dense_attn_strided(q, k, v, q_strides, k_strides, v_strides, o, nullptr, l, B, H, Nq, Nk, stream);
+}
+
+extern "C" int chipmunk_dense_colsum_attn_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                                  const int64_t k_strides[3], const int64_t v_strides[3], const float *pin,
+                                                  void *o, const int64_t *o_strides, void *cs, float *l, int B, int H, int Nq,
+                                                  int Nk, int cs_stride, void *stream) {
     if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
     CM_CHECK(l && cs && pin, "dense_colsum_attn: p / cs / l missing");
     CM_CHECK(cs_stride >= Nk, "dense_colsum_attn: cs row stride %d < Nk %d", cs_stride, Nk);
@@ -963,7 +1006,7 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     AttnParams p = {};
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v, p.o = (uint16_t *)o;
     for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
-    contiguous_strides(p.os, H, Nq);
+    if (int e = output_strides(p.os, o_strides, H, Nq)) return e;
     p.l_out = l, p.p_in = pin, p.cs = (uint16_t *)cs, p.cs_stride = cs_stride;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
@@ -1018,15 +1061,23 @@ extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const vo
     return launch_attn<false, false, false, true>(p, st);
 }
 
+extern "C" int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                          const int64_t k_strides[3], const int64_t v_strides[3], const float *pin,
+                                          void *o, void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride,
+                                          void *stream) {
+    return chipmunk_dense_colsum_attn_strided(q, k, v, q_strides, k_strides, v_strides, pin, o, nullptr, cs, l, B, H, Nq, Nk,
+                                              cs_stride, stream);
+}
+
 // dense attention + the mask-recompute step's key selection in one call: column sums stay in the per-wave partial rows of the
 // one-pass kernel (attn64.hip MODE 3) and the top-k mask kernel adds the three rows of a group itself -- the [B,H,G,Nk] `cs`
 // tensor of the reference (3.55 GB at HunyuanVideo size, written by dense_colsum_attn.cu:267-277 and re-read by
 // modules/attn.py:76-84) is never materialised.  Same bits as chipmunk_dense_colsum_attn followed by chipmunk_topk_mask.
 // Returns CHIPMUNK_ERR_UNSUPPORTED (nothing launched) when the launch does not take the one-pass route in one piece; the
 // caller then runs the two operators.
-extern "C" int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+extern "C" int chipmunk_dense_colsum_topk_mask_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
                                                const int64_t k_strides[3], const int64_t v_strides[3], const float *pin, void *o,
-                                               float *l, int B, int H, int Nq, int Nk, const void *static_mask,
+                                               const int64_t *o_strides, float *l, int B, int H, int Nq, int Nk, const void *static_mask,
                                                int64_t static_stride, int static_rows, const void *group_flags, void *mask,
                                                int topk, double random_amount, void *stream) {
     if (int e = check_common(q, k, v, o, B, H, Nq, Nk)) return e;
@@ -1042,7 +1093,7 @@ extern "C" int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, con
     for (int i = 0; i < 3; ++i) p.qs[i] = q_strides[i], p.ks[i] = k_strides[i], p.vs[i] = v_strides[i];
     CM_CHECK((int64_t)Nk * p.ks[2] * 2 < (1ll << 32) && (int64_t)Nk * p.vs[2] * 2 < (1ll << 32),
              "attention: one head's K or V spans more than 4 GiB (32-bit DMA offsets)");
-    contiguous_strides(p.os, H, Nq);
+    if (int e = output_strides(p.os, o_strides, H, Nq)) return e;
     p.l_out = l, p.p_in = pin, p.cs = nullptr, p.cs_stride = 0;
     p.B = B, p.H = H, p.Nq = Nq, p.Nk = Nk, p.G = (Nq + QG - 1) / QG;
     p.o_scale = 1.f;
@@ -1052,4 +1103,14 @@ extern "C" int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, con
     const int nrb = ((Nq + 255) / 256) * 4;
     return chipmunk_topk_mask_parts(part, nrb, p.G, Nq, static_mask, static_stride, static_rows, group_flags, mask, B * H * p.G, Nk,
                                     topk, random_amount, st);
+}
+
+extern "C" int chipmunk_dense_colsum_topk_mask(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                               const int64_t k_strides[3], const int64_t v_strides[3], const float *pin, void *o,
+                                               float *l, int B, int H, int Nq, int Nk, const void *static_mask,
+                                               int64_t static_stride, int static_rows, const void *group_flags, void *mask,
+                                               int topk, double random_amount, void *stream) {
+    return chipmunk_dense_colsum_topk_mask_strided(q, k, v, q_strides, k_strides, v_strides, pin, o, nullptr, l, B, H, Nq, Nk,
+                                                   static_mask, static_stride, static_rows, group_flags, mask, topk, random_amount,
+                                                   stream);
 }

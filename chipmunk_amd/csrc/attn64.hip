@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // 32 on the unaligned path); at the top of iteration t everything up to iteration t-3 has to have landed -- 72
         // younger operations, more than the counter can express: vmcnt(63), the loosest wait there is, covers it (a single
         // wave cannot keep more than 63 KiB of gathers in flight; key*stride as a 24-bit multiply, checked by the host).
-        const int32_t *idx = p.indices + ((int64_t)bh * p.G + g) * p.idx_stride;
+        const IndexRow irow = index_row(p, (int64_t)bh * p.G + g);
+        const int32_t *idx = irow.ptr;
         uint32_t kswz[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) kswz[i] = (uint32_t)(l15 ^ (4 * i + lg)) << 4;
@@ -205,10 +206,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int ir[4][16];
         // 16 consecutive indices per lane group: four 16-byte loads when the row is 16-byte aligned and the tile lies inside
         // the list (every HunyuanVideo / Wan / FLUX launch), dword loads with clamped positions otherwise
-        const bool idx_vec = ((uintptr_t)idx & 15) == 0 && (p.idx_stride & 3) == 0;
+        const bool idx_vec = ((uintptr_t)idx & 15) == 0 && (irow.width & 3) == 0;
         auto load_idx = [&](int T, int (&dst)[16]) {
             const int base = (tbeg + T) * KT + lg * 16;
-            if (idx_vec && (tbeg + T) * KT + KT <= p.idx_stride) {
+            if (idx_vec && (tbeg + T) * KT + KT <= irow.width) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) {
                     const u32x4 v4 = *(const u32x4 *)(idx + base + j4 * 4);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     int pos = base + j;
-                    pos = pos < p.idx_stride ? pos : p.idx_stride - 1;
+                    pos = pos < irow.width ? pos : irow.width - 1;
                     dst[j] = idx[pos];
                 }
             }

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
     const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
     const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;
-    const int32_t *idx = p.indices + ((int64_t)bh * p.G + g) * p.idx_stride;
+    const IndexRow irow = index_row(p, (int64_t)bh * p.G + g);
+    const int32_t *idx = irow.ptr;
 
     // ---- accumulator file: O^T = 0; Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7)
     asm volatile(A96_ZERO_O ::: A64_CLOBBER_ALL);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t vswz = (uint32_t)(l15 ^ (lg << 2)) << 4;
     // index rows through a buffer resource sized to the row: no 64-bit lane addresses, and positions past the row's end read 0
     // (hardware range check) -- padding tiles are masked, key 0 is as good as any
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, p.idx_stride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, irow.width * 4, 0x00020000);
     const int nk1 = p.Nk - 1;
     auto load_idx = [&](int T) {   // (idx_stride is a multiple of 4 here: launch_attn sends other launches to the general kernel)
         const int base = ((tbeg + T) * KT + w * 16 + lg * 4) * 4;

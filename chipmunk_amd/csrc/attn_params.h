@@ -10,6 +10,9 @@ struct AttnParams {
     const uint16_t *o_in;  // INPLACE only: the accumulation base (o itself for the in-place op, the cache for csp_attn_out)
     int64_t qs[3], ks[3], vs[3], os[3];
     const int32_t *indices, *counts;
+    // ragged index rows (nullptr: row `item` = indices + item * idx_stride, idx_stride entries wide): row `item` = indices +
+    // idx_off[item], idx_off[item + 1] - idx_off[item] entries wide; B*H*G + 1 offsets, each a multiple of 4
+    const int64_t *idx_off;
     float *l_out;
     const float *p_in;
     uint16_t *cs;
@@ -54,3 +57,15 @@ int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
 int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
 // attn64.hip: max_j |k_j| per (batch, head) into library scratch (nullptr if switched off / unavailable); see AttnParams::kmax
 const float *chipmunk_knorm_max(const uint16_t *k, const int64_t ks[3], int B, int H, int Nk, hipStream_t stream);
+
+struct IndexRow {
+    const int32_t *ptr;
+    int width;   // entries that may be read (positions past it are clamped / read as 0)
+};
+__device__ __forceinline__ IndexRow index_row(const AttnParams &p, int64_t item) {
+    if (p.idx_off) {
+        const int64_t o = p.idx_off[item];
+        return {p.indices + o, (int)(p.idx_off[item + 1] - o)};
+    }
+    return {p.indices + item * p.idx_stride, p.idx_stride};
+}

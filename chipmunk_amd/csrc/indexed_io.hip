@@ -502,6 +502,28 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, u
     }
 }
 
+// ragged copy of index rows: row r of `flat` (at offsets[r]) = the first counts[r] entries of row r of `indices`, the rest of
+// the row (up to offsets[r + 1]) zero.  One workgroup per row, 16 bytes per lane when both sides allow.
+__global__ __launch_bounds__(256) void compact_indices_kernel(const int32_t *indices, int64_t idx_stride, const int32_t *counts,
+                                                             const int64_t *offsets, int32_t *flat) {
+    const int64_t r = blockIdx.x;
+    const int32_t *src = indices + r * idx_stride;
+    const int64_t o = offsets[r];
+    int32_t *dst = flat + o;
+    const int width = (int)(offsets[r + 1] - o);
+    int c = counts[r];
+    c = c < 0 ? 0 : (c < width ? c : width);
+    c = c < idx_stride ? c : (int)idx_stride;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int c4 = c >> 2;
+        for (int i = threadIdx.x; i < c4; i += 256) ((u32x4 *)dst)[i] = ((const u32x4 *)src)[i];
+        for (int i = (c4 << 2) + threadIdx.x; i < c; i += 256) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < c; i += 256) dst[i] = src[i];
+    }
+    for (int i = c + threadIdx.x; i < width; i += 256) dst[i] = 0;
+}
+
 size_t m2i_lds_bytes(int n, bool sorted) {
     const int NI = (n + 31) >> 5, NB = (NI + 63) >> 6;
     if (sorted) return (size_t)NB * 64 * 4 + (size_t)(NB + 1) * 4 + 16;   // bit words + block totals: 8 workgroups per CU
@@ -1031,6 +1053,18 @@ extern "C" int chipmunk_topk_mask(const void *cs, int64_t cs_stride, const void 
     else if (n <= 1024 * 48) LAUNCH_TM(48);
     else LAUNCH_TM(120);
 #undef LAUNCH_TM
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_compact_indices(const int32_t *indices, int64_t idx_stride, const int32_t *counts, const int64_t *offsets,
+                                        int32_t *flat, int64_t rows, void *stream) {
+    CM_CHECK(indices && counts && offsets && flat, "compact_indices: null pointer");
+    CM_CHECK(rows >= 0 && rows < (1ll << 31) && idx_stride > 0, "compact_indices: bad sizes rows=%lld idx_stride=%lld", (long long)rows,
+             (long long)idx_stride);
+    if (rows == 0) return CHIPMUNK_OK;
+    hipLaunchKernelGGL(compact_indices_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, indices, idx_stride, counts,
+                       offsets, flat);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

@@ -94,14 +94,62 @@ at::Tensor csp_attn_out(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor o_i
     const int64_t groups = (q.size(2) + 191) / 192;
     check_indices(q, indices, indices_counts, groups);
     c10::DeviceGuard guard(q.device());
-    at::Tensor oi = o_in.contiguous();
-    at::Tensor o = at::empty(q.sizes(), oi.options());
+    // the result takes o_in's layout when that has contiguous 128-element rows (e.g. the token-major cache of a dense call with
+    // token_major_o): o_in and o share one set of strides in the C entry
+    const bool keep = o_in.stride(3) == 1 && o_in.is_non_overlapping_and_dense();
+    at::Tensor oi = keep ? o_in : o_in.contiguous();
+    at::Tensor o = at::empty_strided(oi.sizes(), oi.strides(), oi.options());
     auto qs = strides_of(q, "Q"), ks = strides_of(k, "K"), vs = strides_of(v, "V"), os = strides_of(o, "O");
     check(chipmunk_csp_attn_out(q.data_ptr(), k.data_ptr(), v.data_ptr(), oi.data_ptr(), o.data_ptr(), qs.s, ks.s, vs.s,
                                 os.s, indices.data_ptr<int>(), indices_counts.data_ptr<int>(), (int)q.size(0),
                                 (int)q.size(1), (int)q.size(2), (int)k.size(2), (int)indices.size(3), (int)o_scale,
                                 cur_stream(q)),
           "csp_attn_out");
+    return o;
+}
+
+// addition: padded index rows [B,H,G,W] + counts -> (flat int32 rows back to back, int64 offsets [B*H*G + 1]); every row is
+// rounded up to 32 entries (zero filled) so that whole key tiles can be read, 64 spare entries at the end
+std::vector<at::Tensor> compact_indices(at::Tensor indices, at::Tensor counts) {
+    CHECK_DEV(indices); CHECK_DEV(counts); CHECK_I32(indices); CHECK_I32(counts); CHECK_CONTIG(indices); CHECK_CONTIG(counts);
+    TORCH_CHECK(indices.dim() == 4 && counts.dim() == 3 && indices.size(0) == counts.size(0) && indices.size(1) == counts.size(1) &&
+                indices.size(2) == counts.size(2), "indices must be [B,H,G,W] and counts [B,H,G]");
+    c10::DeviceGuard guard(indices.device());
+    const int64_t rows = counts.numel(), W = indices.size(3);
+    at::Tensor len = counts.flatten().clamp(0, W).to(at::kLong).add_(31).div_(32, "floor").mul_(32);
+    at::Tensor offsets = at::zeros({rows + 1}, len.options());
+    if (rows) offsets.narrow(0, 1, rows).copy_(len.cumsum(0));
+    const int64_t total = rows ? offsets[rows].item<int64_t>() : 0;      // one host sync (a mask-recompute step, not the sparse step)
+    at::Tensor flat = at::empty({total + 64}, indices.options());
+    flat.narrow(0, total, 64).zero_();
+    check(chipmunk_compact_indices(indices.data_ptr<int>(), W, counts.data_ptr<int>(), offsets.data_ptr<int64_t>(), flat.data_ptr<int>(),
+                                   rows, cur_stream(indices)),
+          "compact_indices");
+    return {flat, offsets};
+}
+
+// addition: csp_attn_out over the ragged rows of compact_indices
+at::Tensor csp_attn_out_ragged(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor o_in, at::Tensor indices, at::Tensor offsets,
+                               at::Tensor indices_counts, int64_t o_scale) {
+    check_attn_shapes(q, k, v);
+    CHECK_DEV(o_in); CHECK_BF16(o_in); CHECK_DEV(indices); CHECK_DEV(offsets); CHECK_DEV(indices_counts);
+    CHECK_I32(indices); CHECK_I32(indices_counts); CHECK_CONTIG(indices); CHECK_CONTIG(offsets); CHECK_CONTIG(indices_counts);
+    TORCH_CHECK(offsets.scalar_type() == at::kLong, "offsets must be int64");
+    TORCH_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
+    TORCH_CHECK(o_in.sizes() == q.sizes(), "O must have the shape of Q");
+    const int64_t groups = (q.size(2) + 191) / 192;
+    TORCH_CHECK(indices_counts.dim() == 3 && indices_counts.size(0) == q.size(0) && indices_counts.size(1) == q.size(1) &&
+                indices_counts.size(2) == groups, "counts must be [B, H, ceil(N/192)]");
+    TORCH_CHECK(offsets.numel() == indices_counts.numel() + 1, "offsets must have one entry per (batch, head, group) + 1");
+    c10::DeviceGuard guard(q.device());
+    const bool keep = o_in.stride(3) == 1 && o_in.is_non_overlapping_and_dense();
+    at::Tensor oi = keep ? o_in : o_in.contiguous();
+    at::Tensor o = at::empty_strided(oi.sizes(), oi.strides(), oi.options());
+    auto qs = strides_of(q, "Q"), ks = strides_of(k, "K"), vs = strides_of(v, "V"), os = strides_of(o, "O");
+    check(chipmunk_csp_attn_out_ragged(q.data_ptr(), k.data_ptr(), v.data_ptr(), oi.data_ptr(), o.data_ptr(), qs.s, ks.s, vs.s, os.s,
+                                       indices.data_ptr<int>(), offsets.data_ptr<int64_t>(), indices_counts.data_ptr<int>(),
+                                       (int)q.size(0), (int)q.size(1), (int)q.size(2), (int)k.size(2), (int)o_scale, cur_stream(q)),
+          "csp_attn_out_ragged");
     return o;
 }
 
@@ -126,22 +174,32 @@ at::Tensor csp_128_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor ind
     return o;
 }
 
+// [B, H, N, 128] output of the dense operators: contiguous as the reference's, or (token_major_o, an addition) the permuted view
+// of [B, N, H, 128] storage, which `o.permute(0, 2, 1, 3).reshape(B, N, H * 128)` turns into the next GEMM's operand for free
+static at::Tensor alloc_o(const at::Tensor &q, const at::Tensor &v, bool token_major) {
+    if (!token_major) return at::empty(q.sizes(), v.options().memory_format(at::MemoryFormat::Contiguous));
+    return at::empty({q.size(0), q.size(2), q.size(1), q.size(3)}, v.options()).permute({0, 2, 1, 3});
+}
+
 // reference csrc/attn/dense_attn.cu:246-372
-std::vector<at::Tensor> dense_attn(at::Tensor q, at::Tensor k, at::Tensor v) {
+std::vector<at::Tensor> dense_attn_layout(at::Tensor q, at::Tensor k, at::Tensor v, bool token_major_o) {
     check_attn_shapes(q, k, v);
     c10::DeviceGuard guard(q.device());
     auto qs = strides_of(q, "Q"), ks = strides_of(k, "K"), vs = strides_of(v, "V");
-    at::Tensor o = at::empty(q.sizes(), v.options().memory_format(at::MemoryFormat::Contiguous));
+    at::Tensor o = alloc_o(q, v, token_major_o);
+    auto os = strides_of(o, "O");
     at::Tensor l = at::empty({q.size(0), q.size(1), q.size(2), 1}, q.options().dtype(at::kFloat));
-    check(chipmunk_dense_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs.s, ks.s, vs.s, o.data_ptr(),
-                              l.data_ptr<float>(), (int)q.size(0), (int)q.size(1), (int)q.size(2), (int)k.size(2),
-                              cur_stream(q)),
+    check(chipmunk_dense_attn_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs.s, ks.s, vs.s, o.data_ptr(), os.s,
+                                      l.data_ptr<float>(), (int)q.size(0), (int)q.size(1), (int)q.size(2), (int)k.size(2),
+                                      cur_stream(q)),
           "dense_attn");
     return {o, l};
 }
 
+std::vector<at::Tensor> dense_attn(at::Tensor q, at::Tensor k, at::Tensor v) { return dense_attn_layout(q, k, v, false); }
+
 // reference csrc/attn/dense_colsum_attn.cu:521-668
-std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p) {
+std::vector<at::Tensor> dense_colsum_attn_layout(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p, bool token_major_o) {
     check_attn_shapes(q, k, v);
     CHECK_DEV(p);
     TORCH_CHECK(p.scalar_type() == at::kFloat, "p must be float32");
@@ -153,14 +211,19 @@ std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor
     // the reference's cs has one column per (padded) query position (:580-583: it only ever sees Nk <= Nq); a rank that holds a
     // slice of the query rows against the whole sequence's keys (query-group sharding) gets one column per key
     const int64_t width = std::max<int64_t>(q.size(2), k.size(2));
-    at::Tensor o = at::empty(q.sizes(), v.options().memory_format(at::MemoryFormat::Contiguous));
+    at::Tensor o = alloc_o(q, v, token_major_o);
+    auto os = strides_of(o, "O");
     at::Tensor cs = at::empty({q.size(0), q.size(1), groups, width}, v.options());
     at::Tensor l = at::empty({q.size(0), q.size(1), q.size(2), 1}, q.options().dtype(at::kFloat));
-    check(chipmunk_dense_colsum_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs.s, ks.s, vs.s, p.data_ptr<float>(),
-                                     o.data_ptr(), cs.data_ptr(), l.data_ptr<float>(), (int)q.size(0), (int)q.size(1),
-                                     (int)q.size(2), (int)k.size(2), (int)width, cur_stream(q)),
+    check(chipmunk_dense_colsum_attn_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs.s, ks.s, vs.s, p.data_ptr<float>(),
+                                             o.data_ptr(), os.s, cs.data_ptr(), l.data_ptr<float>(), (int)q.size(0),
+                                             (int)q.size(1), (int)q.size(2), (int)k.size(2), (int)width, cur_stream(q)),
           "dense_colsum_attn");
     return {o, cs, l};
+}
+
+std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p) {
+    return dense_colsum_attn_layout(q, k, v, p, false);
 }
 
 // ---------------------------------------------------------------------------------- MLP
@@ -458,11 +521,12 @@ std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef 
 // addition: randint + topk + scatter_ + the two mask combines of modules/attn.py:76-82 in one kernel
 // dense_colsum_attn + topk_mask without the cs tensor between them (see chipmunk_dense_colsum_topk_mask); falls back to the two
 // operators when the fused entry does not apply to the launch
-std::vector<at::Tensor> dense_colsum_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p);
+std::vector<at::Tensor> dense_colsum_attn_layout(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p, bool token_major_o);
 at::Tensor topk_mask(at::Tensor cs, int64_t k, double random_amount, const c10::optional<at::Tensor> &groups,
                      const c10::optional<at::Tensor> &static_mask);
 std::vector<at::Tensor> dense_colsum_topk_mask(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor p, int64_t k_top, double random_amount,
-                                               const c10::optional<at::Tensor> &groups, const c10::optional<at::Tensor> &static_mask) {
+                                               const c10::optional<at::Tensor> &groups, const c10::optional<at::Tensor> &static_mask,
+                                               bool token_major_o) {
     CHECK_DEV(q); CHECK_DEV(k); CHECK_DEV(v); CHECK_DEV(p);
     CHECK_BF16(q); CHECK_BF16(k); CHECK_BF16(v);
     const bool shapes_ok = q.dim() == 4 && k.dim() == 4 && v.dim() == 4 && q.size(3) == 128 && q.stride(3) == 1 && k.stride(3) == 1 &&
@@ -491,19 +555,20 @@ std::vector<at::Tensor> dense_colsum_topk_mask(at::Tensor q, at::Tensor k, at::T
         }
         if (ok) {
             c10::DeviceGuard guard(q.device());
-            at::Tensor o = at::empty({B, H, Nq, 128}, q.options());
+            at::Tensor o = alloc_o(q, q, token_major_o);
+            const int64_t os[3] = {o.stride(0), o.stride(1), o.stride(2)};
             at::Tensor l = at::empty({B, H, Nq, 1}, q.options().dtype(at::kFloat));
             at::Tensor mask = at::empty({B, H, G, Nk}, q.options().dtype(at::kBool));
             const int64_t qs[3] = {q.stride(0), q.stride(1), q.stride(2)}, ks[3] = {k.stride(0), k.stride(1), k.stride(2)},
                           vs[3] = {v.stride(0), v.stride(1), v.stride(2)};
-            const int rc = chipmunk_dense_colsum_topk_mask(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs, ks, vs, p.data_ptr<float>(), o.data_ptr(),
-                                                           l.data_ptr<float>(), (int)B, (int)H, (int)Nq, (int)Nk, st, st_stride, (int)st_rows, gf,
+            const int rc = chipmunk_dense_colsum_topk_mask_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), qs, ks, vs, p.data_ptr<float>(), o.data_ptr(),
+                                                           os, l.data_ptr<float>(), (int)B, (int)H, (int)Nq, (int)Nk, st, st_stride, (int)st_rows, gf,
                                                            mask.data_ptr(), (int)k_top, random_amount, cur_stream(q));
             if (rc == CHIPMUNK_OK) return {o, mask, l};
             if (rc != CHIPMUNK_ERR_UNSUPPORTED) check(rc, "dense_colsum_topk_mask");
         }
     }
-    auto ocl = dense_colsum_attn(q, k, v, p);
+    auto ocl = dense_colsum_attn_layout(q, k, v, p, token_major_o);
     at::Tensor cs = ocl[1];
     const int64_t Nk = k.size(2), G = (q.size(2) + 191) / 192;
     if (cs.size(-1) != Nk || cs.size(-2) != G) cs = cs.slice(-2, 0, G).slice(-1, 0, Nk);
@@ -646,7 +711,12 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("packed_mask_to_indices(Tensor packed, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("mask_to_sorted_indices(Tensor mask, int[] shape, int multiple_of, int pad_to_multiple_of) -> Tensor[]");
     m.def("topk_mask(Tensor cs, int k, float random_amount, Tensor? groups, Tensor? static_mask) -> Tensor");
-    m.def("dense_colsum_topk_mask(Tensor q, Tensor k, Tensor v, Tensor p, int k_top, float random_amount, Tensor? groups, Tensor? static_mask) -> Tensor[]");
+    m.def("dense_colsum_topk_mask(Tensor q, Tensor k, Tensor v, Tensor p, int k_top, float random_amount, Tensor? groups, Tensor? static_mask, bool token_major_o=False) -> Tensor[]");
+    // the two dense operators with a choice of output layout (the reference's schemas above stay as they are)
+    m.def("dense_attn_layout(Tensor q, Tensor k, Tensor v, bool token_major_o) -> Tensor[]");
+    m.def("dense_colsum_attn_layout(Tensor q, Tensor k, Tensor v, Tensor p, bool token_major_o) -> Tensor[]");
+    m.def("compact_indices(Tensor indices, Tensor counts) -> Tensor[]");
+    m.def("csp_attn_out_ragged(Tensor q, Tensor k, Tensor v, Tensor o_in, Tensor indices, Tensor offsets, Tensor indices_counts, int o_scale) -> Tensor");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -668,6 +738,10 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("csp_128_attn", &csp_128_attn);
     m.impl("dense_attn", &dense_attn);
     m.impl("dense_colsum_attn", &dense_colsum_attn);
+    m.impl("compact_indices", &compact_indices);
+    m.impl("csp_attn_out_ragged", &csp_attn_out_ragged);
+    m.impl("dense_attn_layout", &dense_attn_layout);
+    m.impl("dense_colsum_attn_layout", &dense_colsum_attn_layout);
     m.impl("csp_attn_out", &csp_attn_out);
     m.impl("csp_mlp_mm1_scatter", &csp_mlp_mm1_scatter);
     m.impl("csp_mlp_mm2", &csp_mlp_mm2);

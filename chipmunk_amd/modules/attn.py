@@ -28,6 +28,7 @@ from ..ops.voxel import get_local_indices_with_text
 from ..util.config import GLOBAL_CONFIG, amd_key
 from ..util.layer_counter import LayerCounter
 from ..util.storage import AttnStorage
+from ..util.storage.offloaded_tensor import release_resident, reserve_resident
 
 # shared by all layers, initialised from the sequence shape (reference attn.py:12-14)
 singleton_static_mask: Optional[Tensor] = None
@@ -36,6 +37,11 @@ singleton_video_query_groups: Optional[Tensor] = None
 
 def _cdiv(a: int, b: int) -> int:
     return (a + b - 1) // b
+
+
+def _dense_attn_raw(q: Tensor, k: Tensor, v: Tensor, token_major_o: bool):
+    """The operator itself (no padding of l), as the reference's unpadded path calls it (modules/attn.py:126)."""
+    return torch.ops.chipmunk.dense_attn_layout(q, k, v, True) if token_major_o else torch.ops.chipmunk.dense_attn(q, k, v)
 
 
 class SparseDiffAttn(nn.Module):
@@ -50,6 +56,7 @@ class SparseDiffAttn(nn.Module):
         self.query_group_offset = query_group_offset
         self.storage = AttnStorage(layer_num, init_names=["indices", "out_cache"], slot=storage_slot)
         self.mask_shape = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
+        self._unpacked = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]   # (indices, counts, bytes booked)
 
     # ------------------------------------------------------------------------------------------ static mask
     def initialize_static_mask(self, seq_shape: Tuple, txt_len: int, local_heads_num: int, device: torch.device):
@@ -97,6 +104,31 @@ class SparseDiffAttn(nn.Module):
         return mask
 
     # ------------------------------------------------------------------------------------------ helpers
+    def _remember_indices(self, inds: Tensor, counts: Tensor) -> None:
+        """``attn.keep_unpacked_indices``: keep what the bit-packed mask just stored unpacks to, while that mask itself stays in
+        HBM -- as ragged rows (``ops.compact_indices``: the kept keys back to back; the padded ``[B, H, G, N]`` int32 tensor is 7 GB per
+        HunyuanVideo layer because the text groups keep every key).  One host sync per mask recompute for the total."""
+        inv = self.layer_counter.cur_model_invocation_per_step
+        old, self._unpacked[inv] = self._unpacked[inv], None
+        if old is not None:
+            release_resident(old[3])
+        if not (inds.is_cuda and amd_key("attn", "keep_unpacked_indices") and amd_key("attn", "fused_residual")
+                and self.storage.indices.is_resident()):
+            return
+        if not reserve_resident(0):
+            return
+        flat, offsets = ops.compact_indices(inds, counts)
+        nbytes = 4 * flat.numel() + 8 * offsets.numel() + 4 * counts.numel()
+        if reserve_resident(nbytes):
+            self._unpacked[inv] = (flat, offsets, counts, nbytes)
+
+    def _kept_indices(self):
+        """(flat indices, offsets, counts) of the current model invocation if they were kept and their mask is still resident."""
+        kept = self._unpacked[self.layer_counter.cur_model_invocation_per_step]
+        if kept is not None and GLOBAL_CONFIG["attn"]["should_compress_indices"] and self.storage.indices.is_resident():
+            return kept[:3]
+        return None
+
     def _stored_indices(self, multiple_of: int, bm: int):
         cfg = GLOBAL_CONFIG["attn"]
         if cfg["should_compress_indices"]:
@@ -117,13 +149,14 @@ class SparseDiffAttn(nn.Module):
         do_padding = cfg["pad_qkv_before_kernel"]
         multiple_of = 128 if do_padding else cfg["counts_multiple_of"]
 
+        tm = bool(q.is_cuda and amd_key("attn", "token_major_output"))     # output layout of the dense calls; the sparse ones follow the cache
         if self.layer_num < cfg["first_n_dense_layers"]:
-            o, _ = ops.dense_attn(q, k, v)
+            o, _ = ops.dense_attn(q, k, v, tm)
             return o
 
         if do_full_step:
             if inference_step == 0:
-                o, lse = ops.dense_attn(q, k, v) if do_padding else torch.ops.chipmunk.dense_attn(q, k, v)
+                o, lse = ops.dense_attn(q, k, v, tm) if do_padding else _dense_attn_raw(q, k, v, tm)
                 lse[..., k.shape[-2]:, :] = 0
                 self.storage.set_lse_constants(lse)
                 return o
@@ -136,11 +169,12 @@ class SparseDiffAttn(nn.Module):
                         and amd_key("attn", "fused_topk_mask") and k.shape[-2] <= 122880):
                     # dense attention -> column sums -> mask without the column-sum tensor in between (same bits as the two steps)
                     static, groups = self._static(q.shape[1], _cdiv(q.shape[-2], bm), k.shape[-2])
-                    o, mask, lse = ops.dense_colsum_topk_mask(q, k, v, prev_lse, tk, 0.01, groups, static)
+                    o, mask, lse = ops.dense_colsum_topk_mask(q, k, v, prev_lse, tk, 0.01, groups, static, tm)
                 elif do_padding:
-                    o, bs, lse = ops.dense_colsum_attn(q, k, v, prev_lse)
+                    o, bs, lse = ops.dense_colsum_attn(q, k, v, prev_lse, tm)
                 else:
-                    o, bs, lse = torch.ops.chipmunk.dense_colsum_attn(q, k, v, prev_lse)
+                    o, bs, lse = (torch.ops.chipmunk.dense_colsum_attn_layout(q, k, v, prev_lse, True) if tm else
+                                  torch.ops.chipmunk.dense_colsum_attn(q, k, v, prev_lse))
                 lse[..., k.shape[-2]:, :] = 0
                 self.storage.set_lse_constants(lse)
                 if cfg["should_compress_indices"]:
@@ -157,6 +191,7 @@ class SparseDiffAttn(nn.Module):
                         inds, counts = ops.mask_to_sorted_indices(mask, mask.shape, multiple_of, bm)
                     else:
                         inds, counts = ops.mask_to_indices(mask, multiple_of, bm)
+                    self._remember_indices(inds, counts)
                 else:
                     kseq = k.shape[-2]
                     bs = bs[..., :_cdiv(kseq, bm), :kseq]
@@ -168,7 +203,7 @@ class SparseDiffAttn(nn.Module):
                     self.storage.set_indices(inds)
                     self.storage.set_counts(counts)
             else:
-                o, _ = ops.dense_attn(q, k, v)
+                o, _ = ops.dense_attn(q, k, v, tm)
 
             if not cfg["recompute_mask"]:
                 inds, counts = self._stored_indices(multiple_of, bm)
@@ -186,8 +221,11 @@ class SparseDiffAttn(nn.Module):
             return o
 
         # sparse step
-        inds, counts = self._stored_indices(multiple_of, bm)
         o = self.storage.get_out_cache()
+        kept = self._kept_indices() if (o.is_cuda and amd_key("attn", "fused_residual")) else None
+        if kept is not None:
+            return ops.csp_attn_out_ragged(q, k, v, o, kept[0], kept[1], kept[2], 1)    # cache + delta, index rows as kept
+        inds, counts = self._stored_indices(multiple_of, bm)
         if do_padding:
             if o.is_cuda and amd_key("attn", "fused_residual"):
                 return ops.csp_attn_out(q, k, v, o, inds, counts, 1)   # cache + delta in one kernel; the cache is only read

@@ -5,6 +5,11 @@ a free win").  The in-place ops need nothing (they return ``()``)."""
 import torch
 
 
+def _o_like(q, token_major):
+    B, H, N, D = q.shape
+    return q.new_empty((B, N, H, D)).permute(0, 2, 1, 3) if token_major else q.new_empty((B, H, N, D))
+
+
 def _register():
     lib = torch.library
 
@@ -14,17 +19,31 @@ def _register():
 
     @lib.register_fake("chipmunk::csp_attn_out")
     def _(q, k, v, o_in, indices, indices_counts, o_scale):
-        return torch.empty(q.shape, dtype=o_in.dtype, device=o_in.device)
+        return torch.empty_like(o_in)
+
+    @lib.register_fake("chipmunk::csp_attn_out_ragged")
+    def _(q, k, v, o_in, indices, offsets, indices_counts, o_scale):
+        return torch.empty_like(o_in)
 
     @lib.register_fake("chipmunk::dense_attn")
     def _(q, k, v):
-        return [torch.empty(q.shape, dtype=q.dtype, device=q.device),
+        return [_o_like(q, False), q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
+
+    @lib.register_fake("chipmunk::dense_attn_layout")
+    def _(q, k, v, token_major_o):
+        return [_o_like(q, token_major_o), q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
+
+    @lib.register_fake("chipmunk::dense_colsum_attn_layout")
+    def _(q, k, v, p, token_major_o):
+        groups = (q.shape[2] + 191) // 192
+        return [_o_like(q, token_major_o),
+                q.new_empty((q.shape[0], q.shape[1], groups, max(q.shape[2], k.shape[2]))),
                 q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
 
     @lib.register_fake("chipmunk::dense_colsum_attn")
     def _(q, k, v, p):
         groups = (q.shape[2] + 191) // 192
-        return [torch.empty(q.shape, dtype=q.dtype, device=q.device),
+        return [_o_like(q, False),
                 q.new_empty((q.shape[0], q.shape[1], groups, q.shape[2])),
                 q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
 
@@ -59,10 +78,10 @@ def _register():
         return src.new_empty(shape)
 
     @lib.register_fake("chipmunk::dense_colsum_topk_mask")
-    def _(q, k, v, p, k_top, random_amount, groups, static_mask):
+    def _(q, k, v, p, k_top, random_amount, groups, static_mask, token_major_o=False):
         B, H, Nq, D = q.shape
         G = (Nq + 191) // 192
-        return [q.new_empty((B, H, Nq, D)), q.new_empty((B, H, G, k.shape[2]), dtype=torch.bool),
+        return [_o_like(q, token_major_o), q.new_empty((B, H, G, k.shape[2]), dtype=torch.bool),
                 q.new_empty((B, H, Nq, 1), dtype=torch.float32)]
 
     @lib.register_fake("chipmunk::qkv_split_norm")

@@ -22,17 +22,20 @@ def _last_dim_contiguous(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
-def dense_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Dense attention; returns ``(o [..., n, d], l [..., pad192(n), 1] fp32)`` with ``l[n:] = 0``."""
+def dense_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, token_major_o: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense attention; returns ``(o [..., n, d], l [..., pad192(n), 1] fp32)`` with ``l[n:] = 0``.  ``token_major_o`` (an
+    addition): ``o`` is the ``[B, H, N, D]`` view of ``[B, N, H, D]`` storage, so the model's ``b h s d -> b s (h d)`` is a view;
+    ``csp_attn_out`` on such a tensor keeps the layout."""
     n = q.shape[-2]
-    o, l = torch.ops.chipmunk.dense_attn(_last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v))
+    q, k, v = _last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v)
+    o, l = torch.ops.chipmunk.dense_attn_layout(q, k, v, True) if token_major_o else torch.ops.chipmunk.dense_attn(q, k, v)
     padded = _pad_len(n)
     if padded != n:
         l = F.pad(l, (0, 0, 0, padded - n))
     return o, l
 
 
-def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torch.Tensor
+def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torch.Tensor, token_major_o: bool = False
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Dense attention + 192-row column sums of the probabilities normalised by last step's ``p``.
 
@@ -43,8 +46,11 @@ def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torc
     padded = _pad_len(n)
     assert p.shape[-2] in (n, padded), "p must be the l vector of the previous full step"
     p_rows = p[..., :n, :].contiguous()
-    o, cs, l = torch.ops.chipmunk.dense_colsum_attn(_last_dim_contiguous(q), _last_dim_contiguous(k),
-                                                    _last_dim_contiguous(v), p_rows)
+    q, k, v = _last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v)
+    if token_major_o:
+        o, cs, l = torch.ops.chipmunk.dense_colsum_attn_layout(q, k, v, p_rows, True)
+    else:
+        o, cs, l = torch.ops.chipmunk.dense_colsum_attn(q, k, v, p_rows)
     if padded != n:
         l = F.pad(l, (0, 0, 0, padded - n))
     kseq = k.shape[-2]
@@ -55,7 +61,7 @@ def dense_colsum_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torc
 
 
 def dense_colsum_topk_mask(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: torch.Tensor, k_top: int, random_amount: float,
-                           groups, static_mask) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                           groups, static_mask, token_major_o: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``dense_colsum_attn`` followed by ``topk_mask`` on its column sums, without the ``[..., ceil(N/192), N]`` tensor between
     them (reference ``modules/attn.py:131-141``: 3.55 GB per HunyuanVideo layer).  Returns ``(o, mask, l padded)`` -- the same
     bits as the two calls.  GPU only (CPU tensors take the reference's op sequence in the module)."""
@@ -63,7 +69,8 @@ def dense_colsum_topk_mask(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p:
     padded = _pad_len(n)
     assert p.shape[-2] in (n, padded), "p must be the l vector of the previous full step"
     o, mask, l = torch.ops.chipmunk.dense_colsum_topk_mask(_last_dim_contiguous(q), _last_dim_contiguous(k), _last_dim_contiguous(v),
-                                                           p[..., :n, :].contiguous(), k_top, random_amount, groups, static_mask)
+                                                           p[..., :n, :].contiguous(), k_top, random_amount, groups, static_mask,
+                                                           token_major_o)
     if padded != n:
         l = F.pad(l, (0, 0, 0, padded - n))
     return o, mask, l
@@ -90,4 +97,18 @@ def csp_attn_out(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o_in: torch.
     return torch.ops.chipmunk.csp_attn_out(q, k, v, o_in, indices, indices_counts, o_scale)
 
 
-__all__ = ["csp_attn", "csp_attn_inplace", "csp_attn_out", "dense_attn", "dense_colsum_attn", "dense_colsum_topk_mask"]
+def compact_indices(indices: torch.Tensor, indices_counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Padded index rows ``[B, H, G, W]`` -> ``(flat, offsets)``: the first ``counts`` entries of every row back to back (rows
+    rounded up to 32 entries), ``offsets`` int64 ``[B*H*G + 1]``.  HunyuanVideo: 0.56 GB instead of the 7 GB the padded tensor
+    takes because the text groups keep every key.  One host sync (the total)."""
+    return tuple(torch.ops.chipmunk.compact_indices(indices.contiguous(), indices_counts.contiguous()))
+
+
+def csp_attn_out_ragged(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o_in: torch.Tensor, indices: torch.Tensor,
+                        offsets: torch.Tensor, indices_counts: torch.Tensor, o_scale: int) -> torch.Tensor:
+    """``csp_attn_out`` reading the ragged rows of ``compact_indices``; the same bits as the padded form."""
+    return torch.ops.chipmunk.csp_attn_out_ragged(q, k, v, o_in, indices, offsets, indices_counts, o_scale)
+
+
+__all__ = ["csp_attn", "csp_attn_inplace", "csp_attn_out", "csp_attn_out_ragged", "compact_indices", "dense_attn", "dense_colsum_attn",
+           "dense_colsum_topk_mask"]

@@ -91,6 +91,14 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "attn.fused_colsum_topk": True,
     # sparse MLP step: GEMM1 applies the scatter-add of its own output (one kernel less, no re-read of c / the cache)
     "mlp.fused_scatter": True,
+    # attention outputs as the [B, H, N, D] view of [B, N, H, D] storage: the model's `b h s d -> b s (h d)` in front of the output
+    # projection is then a view instead of a 2 x B*H*N*256-byte copy per layer.  Off by default: same values, but a caller that
+    # `.view()`s the result needs the reference's contiguous layout.
+    "attn.token_major_output": False,
+    # should_compress_indices: while the bit-packed mask stays in HBM (offload off, or kept by keep_resident_if_fits), also keep the
+    # (indices, counts) it unpacks to -- compacted to the widest row, 0.54 GB per HunyuanVideo layer, counted against hbm_budget_gb --
+    # instead of re-deriving them from the bits in every sparse step (0.48 ms per layer)
+    "attn.keep_unpacked_indices": True,
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
@@ -101,6 +109,8 @@ BASE_CONFIG["attn"]["fused_residual"] = AMD_EXTRA_KEYS["attn.fused_residual"]
 BASE_CONFIG["attn"]["fused_topk_mask"] = AMD_EXTRA_KEYS["attn.fused_topk_mask"]
 BASE_CONFIG["attn"]["fused_colsum_topk"] = AMD_EXTRA_KEYS["attn.fused_colsum_topk"]
 BASE_CONFIG["mlp"]["fused_scatter"] = AMD_EXTRA_KEYS["mlp.fused_scatter"]
+BASE_CONFIG["attn"]["token_major_output"] = AMD_EXTRA_KEYS["attn.token_major_output"]
+BASE_CONFIG["attn"]["keep_unpacked_indices"] = AMD_EXTRA_KEYS["attn.keep_unpacked_indices"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
 

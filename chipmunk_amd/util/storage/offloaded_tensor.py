@@ -30,6 +30,33 @@ gpu_tensors: Dict[str, List[Optional[torch.Tensor]]] = {}
 _resident_bytes = 0
 
 
+def _is_dense(t: torch.Tensor) -> bool:
+    """Some permutation of the dimensions is contiguous (the storage has no holes and no overlaps)."""
+    expect = 1
+    for d in sorted(range(t.dim()), key=lambda d: t.stride(d)):
+        if t.size(d) == 1:
+            continue
+        if t.stride(d) != expect:
+            return False
+        expect *= t.size(d)
+    return True
+
+
+def reserve_resident(nbytes: int) -> bool:
+    """Book ``nbytes`` of HBM against ``offloading.hbm_budget_gb`` for a derived tensor a module wants to keep next to its
+    resident cache (``release_resident`` returns them); False = over budget, do not keep it."""
+    global _resident_bytes
+    if _resident_bytes + nbytes > float(amd_key("offloading", "hbm_budget_gb")) * (1 << 30):
+        return False
+    _resident_bytes += nbytes
+    return True
+
+
+def release_resident(nbytes: int) -> None:
+    global _resident_bytes
+    _resident_bytes = max(0, _resident_bytes - nbytes)
+
+
 def _side_stream(kind: str) -> "torch.cuda.Stream":
     if kind not in _streams:
         _streams[kind] = torch.cuda.Stream()
@@ -68,6 +95,7 @@ class MaybeOffloadedTensor:
         self.cpu_buf: List[Optional[torch.Tensor]] = [None] * n_inv   # pinned, allocated on first offload
         self.gpu_tensor: List[Optional[torch.Tensor]] = [None] * n_inv  # resident path
         self.real_shape: List[Optional[torch.Size]] = [None] * n_inv
+        self.real_stride: List[Optional[tuple]] = [None] * n_inv   # a dense permuted layout (token-major o) travels as it is
         self._resident: List[bool] = [False] * n_inv
         self.model_invocation_count = 0
         if self.slot_name not in gpu_tensors:
@@ -101,6 +129,9 @@ class MaybeOffloadedTensor:
         if self._stays_resident(key, gpu_tensor.numel() * gpu_tensor.element_size()):
             self.gpu_tensor[key] = gpu_tensor
             return
+        if not _is_dense(gpu_tensor):
+            gpu_tensor = gpu_tensor.contiguous()
+        self.real_stride[key] = tuple(gpu_tensor.stride())
         buf = self.cpu_buf[key]
         if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype:
             buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
@@ -108,7 +139,8 @@ class MaybeOffloadedTensor:
         side = offload_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            buf[: gpu_tensor.numel()].view(gpu_tensor.shape).copy_(gpu_tensor, non_blocking=True)
+            # same strides on both sides: one hipMemcpyAsync of the storage, whatever the dimension order
+            buf[: gpu_tensor.numel()].as_strided(gpu_tensor.shape, self.real_stride[key]).copy_(gpu_tensor, non_blocking=True)
             gpu_tensor.record_stream(side)
 
     def offload_cur_value(self) -> None:
@@ -141,13 +173,14 @@ class MaybeOffloadedTensor:
         if self._is_resident_now():
             return self.gpu_tensor[key]
         slot = gpu_tensors[self.slot_name][self.layer_key]
-        if slot is None or slot.shape != shape or slot.dtype != self.cpu_buf[key].dtype:
-            slot = torch.empty(shape, dtype=self.cpu_buf[key].dtype, device=self.device)
+        stride = self.real_stride[key]
+        if slot is None or slot.shape != shape or slot.stride() != stride or slot.dtype != self.cpu_buf[key].dtype:
+            slot = torch.empty_strided(shape, stride, dtype=self.cpu_buf[key].dtype, device=self.device)
             gpu_tensors[self.slot_name][self.layer_key] = slot
         side = load_stream()
         side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
         with torch.cuda.stream(side):
-            slot.copy_(self.cpu_buf[key][: slot.numel()].view(shape), non_blocking=True)
+            slot.copy_(self.cpu_buf[key][: slot.numel()].as_strided(shape, stride), non_blocking=True)
             slot.record_stream(side)
         return slot
 

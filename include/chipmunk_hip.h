@@ -67,6 +67,19 @@ int chipmunk_csp_attn_out(const void *q, const void *k, const void *v, const voi
                           const int64_t o_strides[3], const int32_t *indices, const int32_t *counts, int B, int H,
                           int Nq, int Nk, int idx_stride, int o_scale, void *stream);
 
+/* chipmunk_csp_attn_out over RAGGED index rows (no reference counterpart; the reference's index tensor is [B,H,G,Nk] int32 --
+ * 7 GB per HunyuanVideo layer for 0.56 GB of kept keys, which is why its modules store a bit-packed mask and rebuild the indices
+ * in every step, modules/attn.py:95-100,161): row (b,h,g) = indices + idx_offsets[(b*H+h)*G+g], idx_offsets[item+1] -
+ * idx_offsets[item] entries wide (B*H*G+1 int64 offsets, each a multiple of 4; indices 16-byte aligned); counts as before.
+ * chipmunk_compact_indices builds that layout from a padded tensor: flat[offsets[r] + j] = indices[r*idx_stride + j] for
+ * j < counts[r], 0 up to offsets[r+1]. */
+int chipmunk_csp_attn_out_ragged(const void *q, const void *k, const void *v, const void *o_in, void *o_out,
+                                 const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                                 const int64_t o_strides[3], const int32_t *indices, const int64_t *idx_offsets,
+                                 const int32_t *counts, int B, int H, int Nq, int Nk, int o_scale, void *stream);
+int chipmunk_compact_indices(const int32_t *indices, int64_t idx_stride, const int32_t *counts, const int64_t *offsets,
+                             int32_t *flat, int64_t rows, void *stream);
+
 /* Replaces chipmunk::csp_128_attn (reference csrc/attn/csp_128_attn.cu:355-461; schema csrc/chipmunk.cpp:53).
  * Same math, out of place into `o` (contiguous [B,H,Nq,128] bf16, fully overwritten), contiguous q/k/v. */
 int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, const int32_t *indices,
@@ -77,6 +90,24 @@ int chipmunk_csp_128_attn(const void *q, const void *k, const void *v, void *o, 
 int chipmunk_dense_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
                         const int64_t k_strides[3], const int64_t v_strides[3], void *o, float *l, int B, int H,
                         int Nq, int Nk, void *stream);
+
+/* The dense operators with an output layout: o_strides = (batch, head, row) element strides of `o`, rows of 128 contiguous
+ * elements (NULL = contiguous [B,H,Nq,128], i.e. the entries above).  Token-major storage [B,Nq,H,128] -- strides
+ * {Nq*H*128, 128, H*128} -- is what the model's next GEMM reads: the reference's `rearrange(o, "b h s d -> b s (h d)")`
+ * (a 2 x B*H*Nq*256-byte copy after every attention, e.g. hunyuan/modules/models.py:264) becomes a view.  The sparse step
+ * keeps the layout by itself: chipmunk_csp_attn / chipmunk_csp_attn_out take o_strides already. */
+int chipmunk_dense_attn_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                const int64_t k_strides[3], const int64_t v_strides[3], void *o, const int64_t *o_strides,
+                                float *l, int B, int H, int Nq, int Nk, void *stream);
+int chipmunk_dense_colsum_attn_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                       const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
+                                       const int64_t *o_strides, void *cs, float *l, int B, int H, int Nq, int Nk,
+                                       int cs_stride, void *stream);
+int chipmunk_dense_colsum_topk_mask_strided(const void *q, const void *k, const void *v, const int64_t q_strides[3],
+                                            const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
+                                            const int64_t *o_strides, float *l, int B, int H, int Nq, int Nk,
+                                            const void *static_mask, int64_t static_stride, int static_rows,
+                                            const void *group_flags, void *mask, int k_top, double random_amount, void *stream);
 
 /* Replaces chipmunk::dense_colsum_attn (reference csrc/attn/dense_colsum_attn.cu:521-668; schema chipmunk.cpp:55).
  * p [B,H,Nq] fp32 = previous step's l.  cs [B,H,ceil(Nq/192),cs_stride] bf16:
