@@ -83,6 +83,7 @@ def parse_args():
                          "exchange rate and the gathered kernel's per-launch cost)")
     ap.add_argument("--sp-chunks", default="", help="hunyuan_sp: explicit split of the heads into chunks, e.g. 1,2")
     ap.add_argument("--no-projections", action="store_true", help="hunyuan: attention + MLP only (round-2 definition of a step)")
+    ap.add_argument("--no-fused-rowwise", action="store_true", help="hunyuan / wan: the block's residual + LayerNorm + modulate as torch ops")
     ap.add_argument("--no-legs", action="store_true", help="hunyuan: skip the 82 %%, step-caching and q-scale legs")
     ap.add_argument("--qk-scale", type=float, default=4.0, help="hunyuan: q multiplier of the running-maximum-fallback leg")
     ap.add_argument("--sp-no-overlap", action="store_true", help="hunyuan_sp: exchange on the compute stream (reference order)")
@@ -314,6 +315,7 @@ class HunyuanBlock:
     elementwise ops -- model code, not this library; both the sparse loop and the dense comparators run exactly this."""
 
     _rope = {}
+    fused_rowwise = True    # gated residual + LayerNorm + modulate as one pass (chipmunk.residual_ln_modulate); --no-fused-rowwise: torch ops
 
     def __init__(self, kind, dev, hid, ffn, heads, projections=True):
         bf = dict(device=dev, dtype=torch.bfloat16)
@@ -331,8 +333,26 @@ class HunyuanBlock:
 
     @staticmethod
     def _ln_mod(x, shift, scale):
-        xn = torch.nn.functional.layer_norm(x, (x.shape[-1],))
+        if HunyuanBlock.fused_rowwise:
+            import chipmunk_amd.ops as ops_pkg
+            return ops_pkg.residual_ln_modulate(x, None, None, shift, scale, 1e-6)[1]
+        xn = torch.nn.functional.layer_norm(x, (x.shape[-1],), eps=1e-6)
         return torch.addcmul(shift, xn, 1 + scale)
+
+    @staticmethod
+    def _res_ln_mod(x, gate, y, nxt):
+        """x + gate * y, and -- when the next LayerNorm + modulate is known (nxt = its (shift, scale)) -- that as well: (x, xm | None)."""
+        if nxt is None:
+            return torch.addcmul(x, gate, y), None
+        if HunyuanBlock.fused_rowwise:
+            import chipmunk_amd.ops as ops_pkg
+            return ops_pkg.residual_ln_modulate(x, y, gate, nxt[0], nxt[1], 1e-6)
+        x = torch.addcmul(x, gate, y)
+        return x, HunyuanBlock._ln_mod(x, nxt[0], nxt[1])
+
+    def first_mod(self):
+        """(shift, scale) of the LayerNorm + modulate this block opens with: the previous block's closing residual takes it along."""
+        return (self.mod[0], self.mod[1]) if self.projections else None
 
     def _qk_norm(self, h):
         """Projection output -> the attention's operands: split, q / k RMSNorm over the head dimension, head-major layout -- one
@@ -348,12 +368,14 @@ class HunyuanBlock:
                                                            ang.sin().repeat_interleave(2, dim=1).contiguous())
         ops_pkg.qkv_split_norm(h, self.qk_w[0], self.qk_w[1], self.heads, 1e-6, rope[0], rope[1])
 
-    def pre(self, x):
-        """Everything in front of the attention; returns what post() needs (single-stream blocks: the MLP half of linear1)."""
+    def pre(self, x, xm=None):
+        """Everything in front of the attention; returns what post() needs (single-stream blocks: the MLP half of linear1).
+        xm: LayerNorm + modulate of x if the previous block's closing pass already produced it."""
         if not self.projections:
             return None
         hid = self.hid
-        xm = self._ln_mod(x, self.mod[0], self.mod[1])
+        if xm is None:
+            xm = self._ln_mod(x, self.mod[0], self.mod[1])
         if self.kind == "double":
             self._qk_norm(torch.addmm(self.qkv.bias, xm, self.qkv.weight.t()))
             return None
@@ -380,22 +402,22 @@ class HunyuanBlock:
             return o.reshape(o.shape[0], self.hid)
         return o
 
-    def post(self, x, g, attn):
-        """attn: the attention output, token-major [rows, hid] or head-major [1, H, rows, D]."""
+    def post(self, x, g, attn, nxt=None):
+        """attn: the attention output, token-major [rows, hid] or head-major [1, H, rows, D]; nxt: first_mod() of the block that
+        follows (None after the last one).  Returns (x, xm for the next block | None)."""
         hid = self.hid
         if not self.projections:
-            return dense_mlp(x, self.fc1, self.fc2)
+            return dense_mlp(x, self.fc1, self.fc2), None
         attn_flat = self._tokens_first(attn)
         if self.kind == "double":
-            x = torch.addcmul(x, self.mod[2], torch.addmm(self.proj.bias, attn_flat, self.proj.weight.t()))
-            xm = self._ln_mod(x, self.mod[3], self.mod[4])
+            x, xm = self._res_ln_mod(x, self.mod[2], torch.addmm(self.proj.bias, attn_flat, self.proj.weight.t()), (self.mod[3], self.mod[4]))
             g = torch._addmm_activation(self.fc1.bias, xm, self.fc1.weight.t(), use_gelu=True)
-            return torch.addcmul(x, self.mod[5], torch.addmm(self.fc2.bias, g, self.fc2.weight.t()))
+            return self._res_ln_mod(x, self.mod[5], torch.addmm(self.fc2.bias, g, self.fc2.weight.t()), nxt)
         # linear2 over cat(attn, gelu(mlp)) (reference :430) = attn @ W[:, :hid]^T + gelu(mlp) @ W[:, hid:]^T: no concatenated copy
         w = self.lin2.weight
         y = torch.addmm(self.lin2.bias, attn_flat, w[:, :hid].t())
         y.addmm_(g, w[:, hid:].t())                 # in place: the out-of-place form first copies y (0.26 ms)
-        return torch.addcmul(x, self.mod[2], y)
+        return self._res_ln_mod(x, self.mod[2], y, nxt)
 
 
 def sdpa_backend_name():
@@ -623,7 +645,7 @@ class Hunyuan:
                 if kind == "full":
                     kind = "dense0" if inference_step == 0 else "mask"
                 L = len(self.layers)
-                x = self.x
+                x, xm = self.x, None
                 for li, (attn, blk) in enumerate(self.layers):
                     for a in attn:                                         # wait for this block's cache ...
                         if inference_step > 0 or li > 0:
@@ -634,19 +656,19 @@ class Hunyuan:
                         self._attention(li, attn)
                         x = blk.mlp_only(self.x)
                         continue
-                    h = blk.pre(x)
+                    h = blk.pre(x, xm)
                     o = self._attention(li, attn)
-                    x = blk.post(x, h, o)
+                    x, xm = blk.post(x, h, o, self.layers[li + 1][1].first_mod() if li + 1 < L else None)
                 self.step_cache.store(x)
             self.step_events.append((inference_step, kind, ev))
 
     def dense_step(self, how):
         with torch.no_grad():
-            x = self.x
+            x, xm, L = self.x, None, len(self.layers)
             for li, (attn, blk) in enumerate(self.layers):
-                h = blk.pre(x)
+                h = blk.pre(x, xm)
                 o = self._attention(li, attn, how)
-                x = blk.post(x, h, o)
+                x, xm = blk.post(x, h, o, self.layers[li + 1][1].first_mod() if li + 1 < L else None)
 
     def time_dense(self, how, steps=1):
         """1 warm step + `steps` measured steps of the all-dense schedule; seconds per step."""
@@ -782,8 +804,11 @@ class Hunyuan:
                              "bit-packed masks)",
                 "block": ("LayerNorm+modulate, QKV projection, q/k norm, attention, output projection, gated residuals, MLP with tanh-GELU in "
                           "fc1's epilogue (single-stream blocks: the fused linear1 / linear2 weights, computed as two GEMMs each over "
-                          "views, no concatenated copy) -- hipBLASLt GEMMs + torch elementwise ops, dense as in the reference "
-                          "(mlp.is_enabled: false); split + q/k RMSNorm + rotary embedding + head-major layout by chipmunk.qkv_split_norm") if not self.args.no_projections else
+                          "views, no concatenated copy) -- hipBLASLt GEMMs, dense as in the reference (mlp.is_enabled: false); "
+                          + ("gated residual + LayerNorm + modulate as one pass (chipmunk.residual_ln_modulate), " if HunyuanBlock.fused_rowwise else
+                             "torch elementwise ops, ") +
+                          "split + q/k RMSNorm + rotary embedding + head-major layout by chipmunk.qkv_split_norm; attention outputs token-major "
+                          "(attn.token_major_output: the head -> token transpose is a view)") if not self.args.no_projections else
                          "dense fc2(gelu_tanh(fc1(x))) per block (two hipBLASLt GEMMs)",
                 "attn_top_keys": self.cfg["attn"]["top_keys"], "step_caching": bool(self.cfg["step_caching"]["is_enabled"]),
                 "caches": "pinned-host offload" if self.args.offload else "resident in HBM (offloading.keep_resident_if_fits)",
@@ -930,6 +955,7 @@ def launch_only(rank, local_rank, world):
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
+    HunyuanBlock.fused_rowwise = not args.no_fused_rowwise
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_with_ranks(args))
     rank = int(os.environ.get("RANK", "0"))

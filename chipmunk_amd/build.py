@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libchipmunk_hip.so")
 TORCH_EXT = os.path.join(ROOT, "cuda.so")
-HIP_SOURCES = ["attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip"]
+HIP_SOURCES = ["attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "rowwise.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -1,0 +1,132 @@
+// Row-wise passes of the transformer block around the attention / MLP operators (model code in the reference, torch ops there):
+// gated residual + LayerNorm + modulate in one pass over the hidden state.
+//
+// The blocks of the DiT models the reference patches do, between any two GEMMs,
+//     x  = x + gate * y                      (torch.addcmul; examples/hunyuan/hyvideo/modules/models.py:262-275, 431)
+//     xm = LayerNorm(x) * (1 + scale) + shift   (modulate(norm(x)), models.py:184-186, 265-268, 371-372; no affine, eps 1e-6)
+// as three elementwise / normalisation kernels: 8 passes over the [rows, C] bf16 hidden state (read x, y, write x; read x, write
+// xn; read xn, write xm) where 4 suffice (read x, y; write x, xm).  HBM-bound: 4 * rows * C * 2 bytes per call.
+//
+// One wave per row (C = 3 072: 6 x 16 bytes per lane), the row in registers between the two reductions (mean, then the centred
+// sum of squares: the two-pass form, no E[x^2] - E[x]^2 cancellation), 64-lane sums by DPP + lane swaps, no LDS.  A wave keeps
+// its gate / shift / scale vectors in registers and walks rows with the grid's stride.  Rounding points are torch's: bf16 after
+// the residual, bf16 after the normalisation, bf16(1 + scale), bf16 after the modulation.
+#include "common.h"
+
+namespace {
+
+template <int NV, bool RESIDUAL>   // NV 16-byte vectors per lane: C <= 512 * NV
+__global__ __launch_bounds__(256) void residual_ln_modulate_kernel(const uint16_t *x, const uint16_t *y, const uint16_t *gate,
+                                                                   const uint16_t *shift, const uint16_t *scale, uint16_t *x_out,
+                                                                   uint16_t *xm, int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const float inv_c = 1.0f / (float)C;
+    u32x4 g[NV], sh[NV], sc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        g[j] = (RESIDUAL && c < C) ? *(const u32x4 *)(gate + c) : z;
+        sh[j] = c < C ? *(const u32x4 *)(shift + c) : z;
+        sc[j] = c < C ? *(const u32x4 *)(scale + c) : z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // bf16(1 + scale), once per wave
+            float a = 1.0f + __uint_as_float(sc[j][e] << 16), b = 1.0f + __uint_as_float(sc[j][e] & 0xffff0000u);
+            sc[j][e] = pack_bf16x2(a, b);
+        }
+    }
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        float f[NV][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            u32x4 xv = {0u, 0u, 0u, 0u}, yv = xv;
+            if (c < C) {
+                xv = *(const u32x4 *)(x + r * C + c);
+                if constexpr (RESIDUAL) yv = *(const u32x4 *)(y + r * C + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = __uint_as_float(xv[e] << 16), b = __uint_as_float(xv[e] & 0xffff0000u);
+                if constexpr (RESIDUAL) {
+                    a += __uint_as_float(g[j][e] << 16) * __uint_as_float(yv[e] << 16);
+                    b += __uint_as_float(g[j][e] & 0xffff0000u) * __uint_as_float(yv[e] & 0xffff0000u);
+                    round_bf16_pair(a, b);
+                    xv[e] = pack_bf16x2(a, b);
+                }
+                f[j][2 * e] = a, f[j][2 * e + 1] = b;
+                sum += a + b;
+            }
+            if constexpr (RESIDUAL)
+                if (c < C) *(u32x4 *)(x_out + r * C + c) = xv;
+        }
+        const float mean = sum_across_rows(row16_sum(sum)) * inv_c;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool in = (lane + 64 * j) * 8 < C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[j][e] -= mean;
+                ss = in ? __builtin_fmaf(f[j][e], f[j][e], ss) : ss;
+            }
+        }
+        const float var = sum_across_rows(row16_sum(ss)) * inv_c;
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = f[j][2 * e] * rstd, b = f[j][2 * e + 1] * rstd;
+                round_bf16_pair(a, b);
+                a = __builtin_fmaf(a, __uint_as_float(sc[j][e] << 16), __uint_as_float(sh[j][e] << 16));
+                b = __builtin_fmaf(b, __uint_as_float(sc[j][e] & 0xffff0000u), __uint_as_float(sh[j][e] & 0xffff0000u));
+                o[e] = pack_bf16x2(a, b);
+            }
+            if (c < C) *(u32x4 *)(xm + r * C + c) = o;
+        }
+    }
+}
+
+template <int NV>
+void launch_rlm(const void *x, const void *y, const void *gate, const void *shift, const void *scale, void *x_out, void *xm, int64_t rows,
+                int C, float eps, hipStream_t s) {
+    // 4 rows per workgroup at a time; enough workgroups for 8 per CU, the rest of the rows by stride
+    const int64_t want = (rows + 3) / 4;
+    const unsigned grid = (unsigned)(want < 256 * 8 ? want : 256 * 8);
+    if (y)
+        hipLaunchKernelGGL((residual_ln_modulate_kernel<NV, true>), dim3(grid), dim3(256), 0, s, (const uint16_t *)x, (const uint16_t *)y,
+                           (const uint16_t *)gate, (const uint16_t *)shift, (const uint16_t *)scale, (uint16_t *)x_out, (uint16_t *)xm, rows,
+                           C, eps);
+    else
+        hipLaunchKernelGGL((residual_ln_modulate_kernel<NV, false>), dim3(grid), dim3(256), 0, s, (const uint16_t *)x, nullptr, nullptr,
+                           (const uint16_t *)shift, (const uint16_t *)scale, nullptr, (uint16_t *)xm, rows, C, eps);
+}
+
+}  // namespace
+
+extern "C" int chipmunk_residual_ln_modulate(const void *x, const void *y, const void *gate, const void *shift, const void *scale,
+                                             void *x_out, void *xm, int64_t rows, int cols, double eps, void *stream) {
+    CM_CHECK(x && shift && scale && xm, "residual_ln_modulate: null pointer");
+    CM_CHECK((y == nullptr) == (gate == nullptr) && (y == nullptr) == (x_out == nullptr),
+             "residual_ln_modulate: y, gate and x_out come together (all set: residual form; all null: LayerNorm + modulate only)");
+    CM_CHECK(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 512 * 16, "residual_ln_modulate: cols must be a multiple of 8, at most 8192 (got %d)",
+             cols);
+    CM_CHECK(((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)shift | (uintptr_t)scale | (uintptr_t)x_out | (uintptr_t)xm)) & 15) == 0,
+             "residual_ln_modulate: pointers must be 16-byte aligned");
+    if (rows == 0) return CHIPMUNK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (cols + 511) / 512;
+    const float e = (float)eps;
+    if (nv <= 2) launch_rlm<2>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    else if (nv <= 3) launch_rlm<3>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    else if (nv <= 6) launch_rlm<6>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    else if (nv <= 10) launch_rlm<10>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    else launch_rlm<16>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}

@@ -153,6 +153,31 @@ at::Tensor csp_attn_out_ragged(at::Tensor q, at::Tensor k, at::Tensor v, at::Ten
     return o;
 }
 
+// addition (model code in the reference): x + gate * y -> LayerNorm -> * (1 + scale) + shift in one pass; returns {x_out, xm};
+// without y / gate: {x, xm}
+std::vector<at::Tensor> residual_ln_modulate(at::Tensor x, const c10::optional<at::Tensor> &y, const c10::optional<at::Tensor> &gate,
+                                             at::Tensor shift, at::Tensor scale, double eps) {
+    CHECK_DEV(x); CHECK_BF16(x); CHECK_CONTIG(x); CHECK_DEV(shift); CHECK_BF16(shift); CHECK_DEV(scale); CHECK_BF16(scale);
+    TORCH_CHECK(x.dim() >= 2, "x must be [..., rows, cols]");
+    const int64_t C = x.size(-1), rows = x.numel() / C;
+    const bool res = y.has_value() && y->defined();
+    TORCH_CHECK(res == (gate.has_value() && gate->defined()), "y and gate come together");
+    at::Tensor sh = shift.contiguous(), sc = scale.contiguous(), yc, gc, xo;
+    TORCH_CHECK(sh.numel() == C && sc.numel() == C, "shift / scale must have one entry per column");
+    if (res) {
+        yc = *y; gc = gate->contiguous();
+        CHECK_DEV(yc); CHECK_BF16(yc); CHECK_CONTIG(yc); CHECK_DEV(gc); CHECK_BF16(gc);
+        TORCH_CHECK(yc.sizes() == x.sizes() && gc.numel() == C, "y must have the shape of x, gate one entry per column");
+        xo = at::empty_like(x);
+    }
+    c10::DeviceGuard guard(x.device());
+    at::Tensor xm = at::empty_like(x);
+    check(chipmunk_residual_ln_modulate(x.data_ptr(), res ? yc.data_ptr() : nullptr, res ? gc.data_ptr() : nullptr, sh.data_ptr(),
+                                        sc.data_ptr(), res ? xo.data_ptr() : nullptr, xm.data_ptr(), rows, (int)C, eps, cur_stream(x)),
+          "residual_ln_modulate");
+    return {res ? xo : x, xm};
+}
+
 // reference csrc/attn/csp_128_attn.cu:355-461
 at::Tensor csp_128_attn(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor indices, at::Tensor indices_counts) {
     check_attn_shapes(q, k, v);
@@ -717,6 +742,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("dense_colsum_attn_layout(Tensor q, Tensor k, Tensor v, Tensor p, bool token_major_o) -> Tensor[]");
     m.def("compact_indices(Tensor indices, Tensor counts) -> Tensor[]");
     m.def("csp_attn_out_ragged(Tensor q, Tensor k, Tensor v, Tensor o_in, Tensor indices, Tensor offsets, Tensor indices_counts, int o_scale) -> Tensor");
+    m.def("residual_ln_modulate(Tensor x, Tensor? y, Tensor? gate, Tensor shift, Tensor scale, float eps) -> Tensor[]");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
@@ -739,6 +765,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("dense_attn", &dense_attn);
     m.impl("dense_colsum_attn", &dense_colsum_attn);
     m.impl("compact_indices", &compact_indices);
+    m.impl("residual_ln_modulate", &residual_ln_modulate);
     m.impl("csp_attn_out_ragged", &csp_attn_out_ragged);
     m.impl("dense_attn_layout", &dense_attn_layout);
     m.impl("dense_colsum_attn_layout", &dense_colsum_attn_layout);

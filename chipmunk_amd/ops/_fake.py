@@ -21,6 +21,10 @@ def _register():
     def _(q, k, v, o_in, indices, indices_counts, o_scale):
         return torch.empty_like(o_in)
 
+    @lib.register_fake("chipmunk::residual_ln_modulate")
+    def _(x, y, gate, shift, scale, eps):
+        return [torch.empty_like(x) if y is not None else x, torch.empty_like(x)]
+
     @lib.register_fake("chipmunk::csp_attn_out_ragged")
     def _(q, k, v, o_in, indices, offsets, indices_counts, o_scale):
         return torch.empty_like(o_in)

@@ -46,3 +46,16 @@ def qkv_split_norm(qkv: torch.Tensor, q_weight: Optional[torch.Tensor], k_weight
 
 
 __all__ = ["qkv_split_norm"]
+
+
+def residual_ln_modulate(x: torch.Tensor, y: Optional[torch.Tensor], gate: Optional[torch.Tensor], shift: torch.Tensor,
+                         scale: torch.Tensor, eps: float = 1e-6):
+    """The block's row-wise chain between two GEMMs as one HBM pass (``chipmunk_residual_ln_modulate``): with ``y`` and ``gate``
+    ``x = x + gate * y`` first (``models.py:262-275, 431``), then ``xm = LayerNorm(x) * (1 + scale) + shift`` (``modulate(norm(x))``,
+    ``models.py:184-186``; LayerNorm without affine).  Returns ``(x, xm)``.  On CPU tensors: the reference's torch sequence."""
+    if x.is_cuda:
+        return tuple(torch.ops.chipmunk.residual_ln_modulate(x, y, gate, shift, scale, eps))
+    if y is not None:
+        x = torch.addcmul(x, gate, y)
+    xn = torch.nn.functional.layer_norm(x, (x.shape[-1],), eps=eps)
+    return x, torch.addcmul(shift, xn, 1 + scale)

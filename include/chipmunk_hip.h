@@ -121,6 +121,15 @@ int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, cons
                                const int64_t k_strides[3], const int64_t v_strides[3], const float *p, void *o,
                                void *cs, float *l, int B, int H, int Nq, int Nk, int cs_stride, void *stream);
 
+/* Row-wise pass of the block around the operators (torch ops in the reference's model code, e.g.
+ * examples/hunyuan/hyvideo/modules/models.py:184-186, 262-275): with y, gate, x_out set
+ *   x_out = bf16(x + gate * y);  xm = bf16(shift + bf16(LayerNorm(x_out)) * bf16(1 + scale))
+ * and with y = gate = x_out = NULL the LayerNorm + modulate of x alone.  x, y, x_out, xm [rows, cols] bf16 contiguous (x_out may
+ * be x); gate, shift, scale [cols] bf16; LayerNorm over cols without affine, statistics in fp32 (two passes over the row in
+ * registers).  cols % 8 == 0, cols <= 8192, 16-byte aligned pointers.  One read of x and y, one write of x_out and xm. */
+int chipmunk_residual_ln_modulate(const void *x, const void *y, const void *gate, const void *shift, const void *scale,
+                                  void *x_out, void *xm, int64_t rows, int cols, double eps, void *stream);
+
 /* ---------------------------------------------------------------- column-sparse MLP
  * Replaces chipmunk::csp_mlp_mm1 (reference csrc/mlp/csp_mlp_mm1.cu:625-702; schema csrc/chipmunk.cpp:47).
  * For 128-row group g and packed column j < counts[g]:

@@ -126,3 +126,34 @@ def test_qkv_split_norm_matches_the_reference_sequence(n, heads, extra, weights,
             torch.testing.assert_close(o.cpu().float(), r.float(), rtol=1.6e-2, atol=2e-2 if rope else 1e-6)   # two bf16 steps (rotated
             #                                     values are sums of two products: a step of the larger product can exceed 1.6 % of a small sum)
             assert (o.cpu() == r).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("rows,cols,residual", [(1000, 3072, True), (777, 3072, False), (333, 1536, True), (65, 1024, True), (5, 8, False),
+                                                (40, 5120, True), (3, 8192, True)])
+def test_residual_ln_modulate_matches_the_reference_sequence(rows, cols, residual):
+    """chipmunk.residual_ln_modulate = the block's torch sequence x = addcmul(x, gate, y); modulate(LayerNorm(x)) (reference
+    hyvideo/modules/models.py:184-186, 262-275) in one pass.  The residual is bit-exact (one fp32 fma, one rounding, as addcmul); the
+    normalised value is a fp32 quotient whose statistics are summed in another order than torch's, so it can land one bf16 step
+    away (rarely), which the modulation carries through: compared against the fp32 evaluation of the same formula with a two-step
+    tolerance, and element-for-element with torch's bf16 sequence on > 99 % of the entries."""
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd.ops.qkv import residual_ln_modulate
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2.0 + 0.3).to(torch.bfloat16)
+    y = torch.randn(rows, cols, generator=g).to(torch.bfloat16) if residual else None
+    gate = (0.5 * torch.randn(cols, generator=g)).to(torch.bfloat16) if residual else None
+    shift = (0.2 * torch.randn(cols, generator=g)).to(torch.bfloat16)
+    scale = (0.2 * torch.randn(cols, generator=g)).to(torch.bfloat16)
+    rx, rxm = residual_ln_modulate(x, y, gate, shift, scale, 1e-6)                      # CPU: the reference's op sequence
+    to = lambda t: None if t is None else t.to(dev)
+    ox, oxm = residual_ln_modulate(to(x), to(y), to(gate), to(shift), to(scale), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(ox.cpu(), rx), "x + gate * y, rounded once"
+    xf = rx.float()
+    xn = ((xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + 1e-6)).to(torch.bfloat16).float()
+    want = shift.float() + xn * (1 + scale).float()           # (1 + scale is a bf16 tensor in the reference)
+    torch.testing.assert_close(oxm.cpu().float(), want, rtol=1.6e-2, atol=2e-2)
+    assert (oxm.cpu() == rxm).float().mean() > 0.99
+    if not residual:
+        assert ox.data_ptr() == to(x).data_ptr() or torch.equal(ox.cpu(), x)

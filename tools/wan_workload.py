@@ -105,8 +105,13 @@ def build_wan(dev, args, timer):
     del x0, x1
     kinds = []
 
+    fused_rowwise = bench.HunyuanBlock.fused_rowwise
+    ones = torch.ones(HID, **bf)
+
     def ln_mod(x, shift, scale):
-        return torch.addcmul(shift, torch.nn.functional.layer_norm(x, (HID,)), 1 + scale)
+        if fused_rowwise:                                    # LayerNorm + modulate in one pass (chipmunk.residual_ln_modulate)
+            return ops_pkg.residual_ln_modulate(x, None, None, shift, scale, 1e-6)[1]
+        return torch.addcmul(shift, torch.nn.functional.layer_norm(x, (HID,), eps=1e-6), 1 + scale)
 
     def tokens_first(o):
         return o[0].permute(1, 0, 2).reshape(o.shape[2], H * D)
@@ -129,8 +134,12 @@ def build_wan(dev, args, timer):
         cq = torch.addmm(blk["cq"].bias, x, blk["cq"].weight.t()).view(1, M, H, D).transpose(1, 2)
         ckv = torch.addmm(blk["ckv"].bias, ctx[inv], blk["ckv"].weight.t()).view(1, TXT, 2, H, D)
         co = torch.nn.functional.scaled_dot_product_attention(cq, ckv[:, :, 0].transpose(1, 2), ckv[:, :, 1].transpose(1, 2))
-        x = x + torch.addmm(blk["co"].bias, co.transpose(1, 2).reshape(M, HID), blk["co"].weight.t())
-        xm = ln_mod(x, m[3], m[4])
+        y = torch.addmm(blk["co"].bias, co.transpose(1, 2).reshape(M, HID), blk["co"].weight.t())
+        if fused_rowwise:                                    # x + y (gate 1: the product is exact) and the LayerNorm + modulate behind it
+            x, xm = ops_pkg.residual_ln_modulate(x, y, ones, m[3], m[4], 1e-6)
+        else:
+            x = x + y
+            xm = ln_mod(x, m[3], m[4])
         if how == "sparse":
             y = blk["mlp"](xm.unsqueeze(0))[0]
             blk["mlp"].storage.complete_cur_layer()
