@@ -174,3 +174,22 @@ def test_bench_launch_two_kernels_agree_everywhere(dev, bench_launch):
     tol = 1.5e-3 + 1e-2 * b.float().abs()
     bad = d > tol
     assert not bad.any(), f"{int(bad.sum())} elements differ, worst {float(d.max()):.4g} at {[int(x) for x in (d == d.max()).nonzero()[0]]}"
+
+
+def test_bench_launch_ragged_rows_and_token_major_cache(dev, bench_launch):
+    """The shipped sparse step at the bench's size: `csp_attn_out_ragged` over the kept ragged index rows (0.56 GB instead of the 7 GB
+    padded tensor) with a token-major cache, against `csp_attn_out` over the padded rows with the contiguous cache -- bit for bit,
+    all 24 x 621 items (text groups with 119 056 keys and their key slices included)."""
+    import chipmunk_amd.ops as ops
+    L = bench_launch
+    g = torch.Generator(device=dev).manual_seed(5)
+    cache = torch.randn(L["q"].shape, device=dev, dtype=torch.bfloat16, generator=g)
+    ref = ops.csp_attn_out(L["q"], L["k"], L["v"], cache, L["inds"], L["counts"], 1)
+    flat, offsets = ops.compact_indices(L["inds"], L["counts"])
+    assert flat.numel() * 4 < 0.1 * L["inds"].numel() * 4, "the kept keys are a small part of the padded index tensor"
+    B, H, N, D = cache.shape
+    cache_tm = torch.empty(B, N, H, D, device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    cache_tm.copy_(cache)
+    got = ops.csp_attn_out_ragged(L["q"], L["k"], L["v"], cache_tm, flat, offsets, L["counts"], 1)
+    assert got.stride() == cache_tm.stride() and got.permute(0, 2, 1, 3).is_contiguous()
+    assert torch.equal(got, ref)
