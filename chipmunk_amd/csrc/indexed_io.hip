@@ -748,23 +748,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     }
     const uint32_t salt = p.salt ^ (first * 0x27D4EB2Fu);
     const int nsteps = (n + 4095) / 4096;
-#pragma unroll 2
-    for (int j = 0; j < nsteps; ++j) {
-        const int c = 4 * tid + 4096 * j;
-        if (c >= n) break;
-        uint32_t v0 = 0, v1 = 0, sb = 0;
-        if constexpr (ALIGNED) {
-            combined4(c, v0, v1);
-            if (st) sb = *(const uint32_t *)(st + c);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t u = c + e < n ? x[c + e] : 0xffffu;
-                if (e < 2) v0 |= u << (16 * e);
-                else v1 |= u << (16 * (e - 2));
-                if (st && c + e < n) sb |= (uint32_t)st[c + e] << (8 * e);
-            }
-        }
+    auto emit = [&](int c, uint32_t v0, uint32_t v1, uint32_t sb) {
         uint32_t bytes = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -783,6 +767,60 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (c + e < n) out[c + e] = (uint8_t)(bytes >> (8 * e));
+        }
+    };
+    if constexpr (ALIGNED) {
+        // batches of OB steps: every load of a batch (up to three partial rows + the static mask) is in flight before the first
+        // value is used -- one workgroup per CU runs this kernel, so the loop's memory parallelism is what a thread issues itself
+        constexpr int OB = 5;
+        const u32x2 zero2 = {0u, 0u};
+        for (int j0 = 0; j0 < nsteps; j0 += OB) {
+            u32x2 raw[OB][PARTS ? 3 : 1];
+            uint32_t sbv[OB];
+#pragma unroll
+            for (int jj = 0; jj < OB; ++jj) {
+                const int c = 4 * tid + 4096 * (j0 + jj);
+                const bool in = c < n;
+                raw[jj][0] = in ? *(const u32x2 *)(x + c) : zero2;
+                if constexpr (PARTS) {
+                    raw[jj][1] = in && prow > 1 ? *(const u32x2 *)(x + (int64_t)n + c) : zero2;
+                    raw[jj][2] = in && prow > 2 ? *(const u32x2 *)(x + 2 * (int64_t)n + c) : zero2;
+                }
+                sbv[jj] = st && in ? *(const uint32_t *)(st + c) : 0u;
+            }
+#pragma unroll
+            for (int jj = 0; jj < OB; ++jj) {
+                const int c = 4 * tid + 4096 * (j0 + jj);
+                if (c >= n) break;
+                uint32_t v0 = raw[jj][0][0], v1 = raw[jj][0][1];
+                if constexpr (PARTS) {   // the same additions in the same order as combined4 (the selection pass)
+                    float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
+                    float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
+#pragma unroll
+                    for (int r = 1; r < 3; ++r)
+                        if (r < prow) {
+                            const u32x2 y = raw[jj][r];
+                            a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
+                            a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
+                        }
+                    v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
+                }
+                emit(c, v0, v1, sbv[jj]);
+            }
+        }
+    } else {
+        for (int j = 0; j < nsteps; ++j) {
+            const int c = 4 * tid + 4096 * j;
+            if (c >= n) break;
+            uint32_t v0 = 0, v1 = 0, sb = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t u = c + e < n ? x[c + e] : 0xffffu;
+                if (e < 2) v0 |= u << (16 * e);
+                else v1 |= u << (16 * (e - 2));
+                if (st && c + e < n) sb |= (uint32_t)st[c + e] << (8 * e);
+            }
+            emit(c, v0, v1, sb);
         }
     }
 }
