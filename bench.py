@@ -1101,6 +1101,29 @@ def main():
                 "launches_in_timed_region": k["launches"], "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts, "hbm_frac_at_algorithmic_bytes": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    if roof and hunyuan and rank == 0 and not args.no_projections:
+        # context for `frac`: what the vendor library's own bf16 GEMM sustains on THIS box, same run (every MFMA-bound kernel here runs
+        # under the same power-limited clock: ~1.5 GHz against the 2.4 GHz behind the nominal peak)
+        blk = wl.layers[0][1]
+        xg = wl.x
+        def fc2_like():
+            return torch.addmm(blk.fc2.bias, hbuf, blk.fc2.weight.t())
+        with torch.no_grad():
+            hbuf = torch._addmm_activation(blk.fc1.bias, xg, blk.fc1.weight.t(), use_gelu=True)
+            fc2_like()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                fc2_like()
+            e1.record()
+            torch.cuda.synchronize()
+        gms = e0.elapsed_time(e1) / 8
+        gtf = 2.0 * xg.shape[0] * blk.fc2.in_features * blk.fc2.out_features / (gms * 1e-3) / 1e12
+        roof["library_gemm_same_box"] = {"tflops": gtf, "frac_of_peak": gtf / MFMA_BF16_PEAK_TFS, "ms": gms,
+                                         "what": f"hipBLASLt bf16 addmm [{xg.shape[0]}, {blk.fc2.in_features}] x [{blk.fc2.in_features}, {blk.fc2.out_features}] (the block's fc2), 8 launches after the timed region"}
+        del hbuf
+
     if wl and not args.no_legs:
         if wl.sp and world > 1 and "sparse" in mean:
             t_noex = wl.no_exchange_probe()
