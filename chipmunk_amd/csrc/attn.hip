@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         wid = p.plan[2 * wid0];
         if (wid < 0) return;
         const int meta = p.plan[2 * wid0 + 1];
-        sp = meta & 0xffff, nsp = meta >> 16;
-        slot0 = tix = wid0 - sp;
+        sp = meta & 0xff, nsp = (meta >> 8) & 0xff;
+        slot0 = tix = meta >> 16;
     } else if (!CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
         const int k = wid0 - p.split_full;
         tix = k / p.nsplit;
@@ -671,9 +671,14 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 //     scratch and the last arriver merges (same hand-off as the dense key-split tail);
 //   * sliced items go FIRST (longest-first), everything else keeps the natural (head, group) order, which keeps one
 //     head's K/V hot in L2 / Infinity Cache;
-//   * T doubles until the slices fit `max_slices` (the scratch the host reserved); unused plan entries are -1.
+//   * T doubles until the slices fit `max_slices` (the scratch the host reserved); unused plan entries are -1;
+//   * the tail: with B workgroups of about equal length on `slots` resident slots the last B mod slots of them run alone for a whole
+//     item time (HunyuanVideo: 120 of 15 480 = 2.5 % of the launch; Wan2.1: 4 of 2 052 = a fifth of it).  The last R unsliced items
+//     are therefore cut into k = slots / R slices each (>= 8 key tiles per slice, <= 64, within the scratch), placed at the END of
+//     the plan: the final round is full and 1 / k as long.
+// Plan entry: (item | -1, slice | slices << 8 | scratch slot of the item's slice 0 << 16).
 __global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *counts, int32_t *plan, int n, int Nk, int slots,
-                                                        int max_slices, int cap) {
+                                                        int max_slices, int cap, int tail) {
     __shared__ unsigned long long total;
     __shared__ int n_slices, wave_tot[16], base_s, T_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *counts, 
         const int k = slices_of(cnt(i), T);
         if (k > 1) {
             const int base = atomicAdd(&n_slices, k);
-            for (int s2 = 0; s2 < k; ++s2) plan[2 * (base + s2)] = i, plan[2 * (base + s2) + 1] = s2 | (k << 16);
+            for (int s2 = 0; s2 < k; ++s2) plan[2 * (base + s2)] = i, plan[2 * (base + s2) + 1] = s2 | (k << 8) | (base << 16);
         }
     }
     __syncthreads();
@@ -732,13 +737,40 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *counts, 
         }
         if (light) {
             const int e = nh + off + __popcll(bal & ((1ull << lane) - 1ull));
-            plan[2 * e] = i, plan[2 * e + 1] = 1 << 16;
+            plan[2 * e] = i, plan[2 * e + 1] = 1 << 8;
         }
         __syncthreads();
         if (tid == 0) base_s += tot;
         __syncthreads();
     }
-    for (int e = nh + base_s + tid; e < cap; e += 1024) plan[2 * e] = -1, plan[2 * e + 1] = 1 << 16;
+    // ---- tail: the last R unsliced items as k slices each (see above)
+    const int n_light = base_s;
+    const int R = slots > 0 ? (nh + n_light) % slots : 0;
+    int used = nh + n_light;
+    if (tail && R > 0 && R <= n_light && 2 * R <= slots && R <= 1024) {
+        const int tail0 = nh + n_light - R;
+        int item = -1, tiles = 1 << 30;
+        if (tid < R) {
+            item = plan[2 * (tail0 + tid)];
+            tiles = (cnt(item) + KVT - 1) / KVT;
+        }
+        if (tid == 0) T_s = 1 << 30;
+        __syncthreads();
+        atomicMin(&T_s, tiles);
+        __syncthreads();
+        int k = slots / R;
+        k = k > 64 ? 64 : k;
+        k = k > T_s / 8 ? T_s / 8 : k;
+        k = k > (max_slices - nh) / R ? (max_slices - nh) / R : k;
+        if (k >= 2) {
+            if (tid < R)
+                for (int s2 = 0; s2 < k; ++s2)
+                    plan[2 * (tail0 + tid * k + s2)] = item, plan[2 * (tail0 + tid * k + s2) + 1] = s2 | (k << 8) | ((nh + tid * k) << 16);
+            used = tail0 + R * k;
+        }
+        __syncthreads();
+    }
+    for (int e = used + tid; e < cap; e += 1024) plan[2 * e] = -1, plan[2 * e + 1] = 1 << 8;
 }
 
 template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
@@ -788,7 +820,7 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
         if (sc && (size_t)max_slices * sizeof(int32_t) <= TICKET_BYTES) {
             int32_t *plan = (int32_t *)(sc + TICKET_BYTES);
             hipLaunchKernelGGL(attn_plan_kernel, dim3(1), dim3(1024), 0, stream, p.counts, plan, (int)nblocks, p.Nk, slots,
-                               max_slices, (int)cap);
+                               max_slices, (int)cap, chipmunk_get_option("attn_no_tail") ? 0 : 1);
             pp.plan = plan;
             pp.tickets = (int32_t *)sc;
             pp.ws = (float *)(sc + ws_off);

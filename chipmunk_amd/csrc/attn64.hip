@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wid = p.plan[2 * wid0];
         if (wid < 0) return;
         const int meta = p.plan[2 * wid0 + 1];
-        sp = meta & 0xffff, nsp = meta >> 16;
-        slot0 = tix = wid0 - sp;
+        sp = meta & 0xff, nsp = (meta >> 8) & 0xff;
+        slot0 = tix = meta >> 16;
     }
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;

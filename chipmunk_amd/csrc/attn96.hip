@@ -78,8 +78,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     wid = p.plan[2 * wid0];
     if (wid < 0) return;
     const int meta = p.plan[2 * wid0 + 1];
-    const int sp = meta & 0xffff, nsp = meta >> 16;
-    const int slot0 = wid0 - sp, tix = wid0 - sp;
+    const int sp = meta & 0xff, nsp = (meta >> 8) & 0xff;   // (attn_plan_kernel: slice | slices << 8 | scratch slot of slice 0 << 16)
+    const int slot0 = meta >> 16, tix = meta >> 16;
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
     const int row0 = g * 192 + w * 96;

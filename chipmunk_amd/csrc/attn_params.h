@@ -24,8 +24,8 @@ struct AttnParams {
     int split_full, nsplit;
     float *ws;
     int32_t *tickets;
-    // optional work plan for ragged key counts (attn_plan_kernel): block i processes item plan[2i] (< 0: nothing), slice
-    // (plan[2i+1] & 0xffff) of (plan[2i+1] >> 16) slices over the item's key tiles; slices of one item are adjacent
+    // optional work plan (attn_plan_kernel): block i processes item plan[2i] (< 0: nothing), slice (m & 0xff) of ((m >> 8) & 0xff)
+    // slices over the item's key tiles, m = plan[2i+1]; m >> 16 = scratch slot (and ticket) of the item's slice 0; slices of one item are adjacent
     const int32_t *plan;
     int xcd_chunks;  // 1: every XCD walks its own contiguous (head, group) range; 0: all XCDs sweep one head together
     // attn64.hip / attn96.hip: per (batch, head) the largest Euclidean norm of a K row (knorm_max_kernel), or nullptr.  With it
