@@ -6,7 +6,7 @@ import torch
 import chipmunk_amd
 from chipmunk_amd import ops
 dev = torch.device("cuda:0")
-H, N = int(os.environ.get("KB_HEADS", "6")), 119056
+H, N = int(os.environ.get("KB_HEADS", "6")), int(os.environ.get("KB_N", "119056"))
 G = (N + 191) // 192
 g = torch.Generator(device=dev).manual_seed(3)
 q, k, v = [torch.randn(1, H, N, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3)]
@@ -21,8 +21,8 @@ def t(fn, n=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 ops.manual_seed(1)
-full = t(lambda: ops.dense_colsum_topk_mask(q, k, v, l, 5888, 0.01, gr, st))
+full = t(lambda: ops.dense_colsum_topk_mask(q, k, v, l, int(os.environ.get("KB_TOPK", "5888")), 0.01, gr, st))
 dense = t(lambda: torch.ops.chipmunk.dense_attn(q, k, v))
 o, cs, _ = torch.ops.chipmunk.dense_colsum_attn(q, k, v, l)
-tk = t(lambda: ops.topk_mask(cs[..., :G, :N], 5888, 0.01, gr, st), 5)
+tk = t(lambda: ops.topk_mask(cs[..., :G, :N], int(os.environ.get("KB_TOPK", "5888")), 0.01, gr, st), 5)
 print(f"H={H}: dense_colsum_topk_mask {full:.2f} ms; dense_attn {dense:.2f} ms; ratio {full / dense:.3f}; topk_mask on cs {tk:.3f} ms")
