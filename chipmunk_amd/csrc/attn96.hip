@@ -337,10 +337,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int VSL = (SL + 3) & 3;        // slot of V(t-1)
         constexpr int KNSL = (SL + 1) & 3;       // slot of K(t+1)
         // K(t+1) and V(t-1) were issued three iterations ago; an iteration is 8 pieces + 1 (4) index loads
-        if constexpr (!(A96_ABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+        if constexpr (!(A96_ABL & (4 | 128))) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // (ablation 128: no wait, 64: no barrier)
+        if constexpr (!(A96_ABL & (4 | 64))) __builtin_amdgcn_s_barrier();
         P96_MARK(0);
         if constexpr (!(A96_ABL & 4)) ir[(SL + 1) & 3] = load_idx(t + 5);
         const int vl_cur = t < ntiles ? valid - (tbeg + t) * KT : 0;   // packed positions of this tile that exist

@@ -6,7 +6,9 @@ import collections, csv, glob, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "chipmunk_amd", "lib", "libchipmunk_hip.so")
-SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
+sys.path.insert(0, ROOT)
+from chipmunk_amd.build import HIP_SOURCES
+SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in HIP_SOURCES]
 path = lambda m: os.path.join(ROOT, "tools", "bin", f"libchipmunk_a96_{m}.so")
 if sys.argv[1:2] == ["build"]:
     os.makedirs(os.path.join(ROOT, "tools", "bin"), exist_ok=True)
