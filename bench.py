@@ -801,7 +801,7 @@ class Hunyuan:
         return {"workload": ("hunyuan_sp" if self.sp else "hunyuan_c3") + f": {shape}, {self.n_img} image + "
                 f"{self.txt} text tokens, 24 heads x 128, hidden 3072, mlp 12288, {blocks} (first 2 attention layers dense)",
                 "attention": "SparseDiffAttn, configs/hunyuan_c3.yml (full steps {0,1,10,40}, top 5% + 1% random + text columns, "
-                             "bit-packed masks)",
+                             "bit-packed masks; while they stay in HBM the kept keys are also held as ragged index rows, attn.keep_unpacked_indices)",
                 "block": ("LayerNorm+modulate, QKV projection, q/k norm, attention, output projection, gated residuals, MLP with tanh-GELU in "
                           "fc1's epilogue (single-stream blocks: the fused linear1 / linear2 weights, computed as two GEMMs each over "
                           "views, no concatenated copy) -- hipBLASLt GEMMs, dense as in the reference (mlp.is_enabled: false); "
