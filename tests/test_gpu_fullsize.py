@@ -384,3 +384,50 @@ def test_c5_wan_attention_shapes(dev):
         ref = oracle.csp_128_attn(qc[:, h:h + 1, r0:r1].contiguous(), kc[:, h:h + 1].contiguous(), vc[:, h:h + 1].contiguous(),
                                   ic[:, h:h + 1, gi:gi + 1, :N].contiguous(), counts[:, h:h + 1, gi:gi + 1].cpu().contiguous())
         assert_close_bf16(o[:, h:h + 1, r0:r1], ref, what=f"Wan sparse head {h} group {gi} vs oracle")
+
+
+@pytest.mark.gpu
+def test_plan_tail_cut_items_match_uncut_and_oracle():
+    """The work plan's tail: 3 heads x 172 groups = 516 equal items on 512 resident slots leave 4 items for a round of their own;
+    the plan cuts each of them into 16 slices (8 key tiles per slice), merged by the last arriver.  The other 512 items must not
+    change by a bit against the plan without the cut (option attn_no_tail), the 4 cut ones agree with it to bf16 rounding and with
+    the oracle, and the launch is run-to-run identical; both kernels that read the plan (attn96.hip, the general kernel)."""
+    from chipmunk_amd import _native
+    dev = torch.device("cuda:0")
+    H, N, keep = 3, 33000, 4096     # (4 096 keys: below 1.5 x the plan's slice size, so no item is cut for length)
+    G = (N + 191) // 192
+    assert (H * G) % 512 == 4
+    g = torch.Generator().manual_seed(91)
+    q, k, v = [randn_bf16(1, H, N, 128, seed=60 + s) for s in range(3)]
+    inds = torch.empty(1, H, G, N, dtype=torch.int32)
+    for h in range(H):
+        for gi in range(G):
+            inds[0, h, gi] = torch.randperm(N, generator=g).to(torch.int32)
+    inds[..., :keep] = inds[..., :keep].sort(-1).values
+    counts = torch.full((1, H, G), keep, dtype=torch.int32)
+    qd, kd, vd, indd, cntd = [t.to(dev) for t in (q, k, v, inds, counts)]
+    tail_rows = torch.zeros(H, G, dtype=torch.bool)
+    tail_rows[H - 1, G - 4:] = True                     # the last four items of the (head, group) order
+    for opt in (0, 2):                                   # attn96.hip (the shipped selection at this size), then the general kernel
+        _native.set_option("attn_csp96", opt)
+        try:
+            o_cut = torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd)
+            assert torch.equal(o_cut, torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd)), "run to run identical"
+            _native.set_option("attn_no_tail", 1)
+            try:
+                o_plain = torch.ops.chipmunk.csp_128_attn(qd, kd, vd, indd, cntd)
+            finally:
+                _native.set_option("attn_no_tail", 0)
+        finally:
+            _native.set_option("attn_csp96", 0)
+        same = (o_cut == o_plain).all(dim=-1)[0].cpu()                                  # [H, N] rows that did not change
+        row_is_tail = tail_rows.repeat_interleave(192, dim=1)[:, :N]
+        assert bool(same[~row_is_tail].all()), "items outside the tail are computed exactly as without the cut"
+        assert not bool(same[row_is_tail].all()), "the four tail items went through the slice merge"
+        d = (o_cut.float() - o_plain.float()).abs().max().item()
+        assert d <= 2.0 ** -7 * max(1e-3, o_plain.float().abs().max().item()), d
+        for gi in (G - 4, G - 1):
+            r0, r1 = gi * 192, min(N, gi * 192 + 192)
+            o_ref = oracle.csp_128_attn(q[:, H - 1:, r0:r1].contiguous(), k[:, H - 1:], v[:, H - 1:], inds[:, H - 1:, gi:gi + 1].contiguous(),
+                                        counts[:, H - 1:, gi:gi + 1].contiguous())
+            assert_close_bf16(o_cut[:, H - 1:, r0:r1], o_ref, what=f"cut item (head {H - 1}, group {gi}) vs oracle, attn_csp96={opt}")
