@@ -665,18 +665,22 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
         uint32_t res = 0;
         for (int bit = 15; bit >= 0; --bit) {
             const uint32_t cand = res | (1u << bit);
-            const uint32_t off = 0x10000u - cand;  // (half + off) >> 16 == (half >= cand)
-            int mine = 0;
+            // both 16-bit keys of a word at once: sat(key - (cand - 1)) is non-zero iff key >= cand; min(., 1) makes it a count;
+            // packed u16 counters (a thread holds at most 4 * NV <= 480 keys).  Three VALU operations per two keys (the 32-bit
+            // form took eight): this loop is 16 rounds x NV * 2 words x 16 waves on one CU's four SIMDs, the kernel's longest phase
+            const uint32_t cm1 = (cand - 1u) | ((cand - 1u) << 16);
+            const uint32_t one2 = 0x00010001u;
+            uint32_t cnt2 = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    uint32_t kw = key[j][h];
-                    // opaque to the optimiser: otherwise it hoists the unpacked halves of all NV*2 words out of the
-                    // 16 rounds (4 * NV more live registers)
-                    asm volatile("" : "+v"(kw));
-                    mine += (int)(((kw & 0xffffu) + off) >> 16) + (int)(((kw >> 16) + off) >> 16);
+                    uint32_t d;
+                    // (asm also keeps the optimiser from hoisting per-word work out of the 16 rounds)
+                    asm volatile("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(d) : "v"(key[j][h]), "v"(cm1), "v"(one2));
+                    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(cnt2) : "v"(d));
                 }
+            const int mine = (int)(cnt2 & 0xffffu) + (int)(cnt2 >> 16);
             if (block_count(mine) >= k) res = cand;
         }
         thr = res;
