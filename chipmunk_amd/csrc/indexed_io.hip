@@ -752,11 +752,14 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     }
     const uint32_t salt = p.salt ^ (first * 0x27D4EB2Fu);
     const int nsteps = (n + 4095) / 4096;
-    auto emit = [&](int c, uint32_t v0, uint32_t v1, uint32_t sb) {
+    // keyed: v0 / v1 hold the order-preserving keys already (the selection's registers), else raw bf16 bits
+    auto emit = [&](auto keyed, int c, uint32_t v0, uint32_t v1, uint32_t sb) {
         uint32_t bytes = 0;
+        if constexpr (decltype(keyed)::value) asm volatile("" : "+v"(v0), "+v"(v1));   // opaque: no unpacking of all NV * 2 words ahead of time
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t kv = bf16_key(((e < 2 ? v0 : v1) >> (16 * (e & 1))) & 0xffffu);
+            const uint32_t half = ((e < 2 ? v0 : v1) >> (16 * (e & 1))) & 0xffffu;
+            const uint32_t kv = decltype(keyed)::value ? half : bf16_key(half);
             bool keep = kv > thr;                      // thr = 0x10000 when the row is inactive or k = 0
             const bool tie = kv == thr && tie_budget > 0 && c + e < n;
             tie_budget -= tie ? 1 : 0;
@@ -774,43 +777,29 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
         }
     };
     if constexpr (ALIGNED) {
-        // batches of OB steps: every load of a batch (up to three partial rows + the static mask) is in flight before the first
-        // value is used -- one workgroup per CU runs this kernel, so the loop's memory parallelism is what a thread issues itself
+        // straight from the selection's key registers (no second pass over the column sums: with PARTS that was three rows again);
+        // the static-mask words of OB steps are in flight together -- one workgroup per CU runs this kernel, so the loop's memory
+        // parallelism is what a thread issues itself.  (Unrolled over all NV steps with the loads batched like this it stays under
+        // the 128 registers of a 1024-thread workgroup; hoisting every load first is what spilled in round 2.)
         constexpr int OB = 5;
-        const u32x2 zero2 = {0u, 0u};
-        for (int j0 = 0; j0 < nsteps; j0 += OB) {
-            u32x2 raw[OB][PARTS ? 3 : 1];
+#pragma unroll
+        for (int j0 = 0; j0 < NV; j0 += OB) {
             uint32_t sbv[OB];
 #pragma unroll
             for (int jj = 0; jj < OB; ++jj) {
                 const int c = 4 * tid + 4096 * (j0 + jj);
-                const bool in = c < n;
-                raw[jj][0] = in ? *(const u32x2 *)(x + c) : zero2;
-                if constexpr (PARTS) {
-                    raw[jj][1] = in && prow > 1 ? *(const u32x2 *)(x + (int64_t)n + c) : zero2;
-                    raw[jj][2] = in && prow > 2 ? *(const u32x2 *)(x + 2 * (int64_t)n + c) : zero2;
-                }
-                sbv[jj] = st && in ? *(const uint32_t *)(st + c) : 0u;
+                sbv[jj] = (j0 + jj < NV && st && c < n) ? *(const uint32_t *)(st + c) : 0u;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < OB; ++jj) {
-                const int c = 4 * tid + 4096 * (j0 + jj);
-                if (c >= n) break;
-                uint32_t v0 = raw[jj][0][0], v1 = raw[jj][0][1];
-                if constexpr (PARTS) {   // the same additions in the same order as combined4 (the selection pass)
-                    float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
-                    float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
-#pragma unroll
-                    for (int r = 1; r < 3; ++r)
-                        if (r < prow) {
-                            const u32x2 y = raw[jj][r];
-                            a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
-                            a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
-                        }
-                    v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
+                if constexpr (true) {
+                    const int c = 4 * tid + 4096 * (j0 + jj);
+                    if (j0 + jj < NV && c < n) emit(std::integral_constant<int, 1>{}, c, key[(j0 + jj) < NV ? (j0 + jj) : 0][0], key[(j0 + jj) < NV ? (j0 + jj) : 0][1], sbv[jj]);
+                    asm volatile("" ::: "memory");   // one step's work at a time (the scheduler otherwise interleaves all NV and spills)
                 }
-                emit(c, v0, v1, sbv[jj]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         for (int j = 0; j < nsteps; ++j) {
@@ -824,7 +813,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
                 else v1 |= u << (16 * (e - 2));
                 if (st && c + e < n) sb |= (uint32_t)st[c + e] << (8 * e);
             }
-            emit(c, v0, v1, sb);
+            emit(std::integral_constant<int, 0>{}, c, v0, v1, sb);
         }
     }
 }

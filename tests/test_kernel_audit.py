@@ -84,3 +84,22 @@ def test_attn96_slot_tables_are_current(tmp_path):
         assert open(hdr).read() == before
     finally:
         open(hdr, "w").write(before)
+
+
+def test_topk_mask_kernels_do_not_spill(tmp_path):
+    """topk_mask_kernel keeps a row's keys in registers (60 packed VGPRs at 119 056 columns, 1024 threads = 128 VGPRs per thread) and
+    writes the mask from them in an unrolled loop: one hoisted unpacking of the keys and it spills 89 registers (seen).  Every
+    instantiation must compile without spills or scratch."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    text = _asm(tmp_path, "indexed_io")
+    names = re.findall(r"\.name:\s+(\S+)", text)
+    scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
+    spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(names) == len(scratch) == len(spills)
+    seen = 0
+    for kname, sc, sp in zip(names, scratch, spills):
+        if "topk_mask_kernel" in kname:
+            assert int(sp) == 0 and int(sc) == 0, f"{kname}: {sp} spills, {sc} bytes of scratch"
+            seen += 1
+    assert seen >= 6
