@@ -97,8 +97,67 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const IndexRow irow = index_row(p, (int64_t)bh * p.G + g);
     const int32_t *idx = irow.ptr;
 
-    // ---- accumulator file: O^T = 0; Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7)
-    asm volatile(A96_ZERO_O ::: A64_CLOBBER_ALL);
+    // ---- lane-constant LDS addresses (tile = [32 rows][256 B]; K chunk swizzle c ^ (r & 15), V chunk swizzle c ^ ((r & 3) << 2))
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    uint32_t kad[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kad[ks] = lds0 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4);
+    const uint32_t qad = lds0 + QLDS + w * 8192 + l31 * 256;   // + (((2*ks + hf) ^ l15) << 4) = kad[ks] - lds0 - l31*256
+    uint32_t vad[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+        vad[db] = lds0 + VRING + (4 * hf + (l15 >> 2)) * 256 + (((db * 4 + 2 * (lg & 1) + ((l15 & 3) >> 1)) ^ ((l15 >> 2) << 2)) << 4) +
+                  (l15 & 1) * 8;
+    // DMA: wave w stages pieces 4w + i, i = 0..3, of the K tile and of the V tile; LDS row 4*(4w+i) + lg <- packed position
+    // w*16 + lg*4 + i of the tile
+    uint32_t kswz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kswz[i] = (uint32_t)(l15 ^ (4 * i + lg)) << 4;
+    const uint32_t vswz = (uint32_t)(l15 ^ (lg << 2)) << 4;
+    // index rows through a buffer resource sized to the row: no 64-bit lane addresses, and positions past the row's end read 0
+    // (hardware range check) -- padding tiles are masked, key 0 is as good as any
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, irow.width * 4, 0x00020000);
+    const int nk1 = p.Nk - 1;
+    auto load_idx = [&](int T) {   // (idx_stride is a multiple of 4 here: launch_attn sends other launches to the general kernel)
+        const int base = ((tbeg + T) * KT + w * 16 + lg * 4) * 4;
+        u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(irsrc, base, 0, 0);
+        return v4;   // raw: clamped at first use, an iteration later (a clamp here would wait for the load and every DMA in flight)
+    };
+    auto clamp_idx = [&](u32x4 &v4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // memory safety for malformed indices: clamp to [0, Nk-1] (one v_med3 each)
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(v4[e]) : "v"(v4[e]), "v"(nk1));
+    };
+    auto issue_k1 = [&](const u32x4 &keys, int slot, int i) {
+        blds16(krsrc, __umul24(keys[i], kstride_b) + kswz[i], 0, smem + slot * TB + (4 * w + i) * 1024);
+    };
+    auto issue_v1 = [&](const u32x4 &keys, int slot, int i) {
+        blds16(vrsrc, __umul24(keys[i], vstride_b) + vswz, 0, smem + VRING + slot * TB + (4 * w + i) * 1024);
+    };
+    auto issue_k = [&](const u32x4 &keys, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_k1(keys, slot, i);
+    };
+    auto issue_v = [&](const u32x4 &keys, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_v1(keys, slot, i);
+    };
+
+    // ---- prologue.  Order matters for a lone wave (nothing else runs on its SIMD while it waits): the index loads go out FIRST, the
+    //      accumulator file is zeroed while they fly, then the gathers of K(0..3) / V(0..1) are issued and only then Q is loaded and
+    //      folded -- Q's load and arithmetic overlap the gather's latency instead of preceding it (three serial round trips -> two).
+    //      K(0); "iterations" -3..-1 (iteration i issues K(i+4) and V(i+2); V(-1) does not exist: V(0) goes into
+    //      its slot so that the first tile's PV -- P = 0 -- multiplies finite numbers)
+    u32x4 ir[4];   // gather keys of four tiles (entry = tile mod 4)
+    ir[0] = load_idx(0), ir[1] = load_idx(1), ir[2] = load_idx(2), ir[3] = load_idx(3);
+    asm volatile(A96_ZERO_O ::: A64_CLOBBER_ALL);   // accumulator file: O^T = 0
+    clamp_idx(ir[0]), clamp_idx(ir[1]), clamp_idx(ir[2]), clamp_idx(ir[3]);
+    issue_k(ir[0], 0);
+    issue_k(ir[1], 1), issue_v(ir[0], 3);
+    issue_k(ir[2], 2), issue_v(ir[0], 0);
+    issue_k(ir[3], 3), issue_v(ir[1], 1);
+    ir[0] = load_idx(4);
+    // ---- Q^T fragments (B operand: lane = query l31, d = ks*16 + hf*8 .. +7); the accumulator file was zeroed above
     // block 0 in 32 VGPRs, block 2 in a[224:255], block 1 staged in LDS (its 32 registers do not fit beside the softmax) and
     // streamed through a two-fragment window, one ds_read_b128 per k step and tile
     u32x4 qv[8];
@@ -151,62 +210,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!nomax) load_q(ic<0>{});
     }
 
-    // ---- lane-constant LDS addresses (tile = [32 rows][256 B]; K chunk swizzle c ^ (r & 15), V chunk swizzle c ^ ((r & 3) << 2))
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    uint32_t kad[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kad[ks] = lds0 + l31 * 256 + (((2 * ks + hf) ^ l15) << 4);
-    const uint32_t qad = lds0 + QLDS + w * 8192 + l31 * 256;   // + (((2*ks + hf) ^ l15) << 4) = kad[ks] - lds0 - l31*256
-    uint32_t vad[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-        vad[db] = lds0 + VRING + (4 * hf + (l15 >> 2)) * 256 + (((db * 4 + 2 * (lg & 1) + ((l15 & 3) >> 1)) ^ ((l15 >> 2) << 2)) << 4) +
-                  (l15 & 1) * 8;
-    // DMA: wave w stages pieces 4w + i, i = 0..3, of the K tile and of the V tile; LDS row 4*(4w+i) + lg <- packed position
-    // w*16 + lg*4 + i of the tile
-    uint32_t kswz[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kswz[i] = (uint32_t)(l15 ^ (4 * i + lg)) << 4;
-    const uint32_t vswz = (uint32_t)(l15 ^ (lg << 2)) << 4;
-    // index rows through a buffer resource sized to the row: no 64-bit lane addresses, and positions past the row's end read 0
-    // (hardware range check) -- padding tiles are masked, key 0 is as good as any
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, irow.width * 4, 0x00020000);
-    const int nk1 = p.Nk - 1;
-    auto load_idx = [&](int T) {   // (idx_stride is a multiple of 4 here: launch_attn sends other launches to the general kernel)
-        const int base = ((tbeg + T) * KT + w * 16 + lg * 4) * 4;
-        u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(irsrc, base, 0, 0);
-        return v4;   // raw: clamped at first use, an iteration later (a clamp here would wait for the load and every DMA in flight)
-    };
-    auto clamp_idx = [&](u32x4 &v4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)   // memory safety for malformed indices: clamp to [0, Nk-1] (one v_med3 each)
-            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(v4[e]) : "v"(v4[e]), "v"(nk1));
-    };
-    auto issue_k1 = [&](const u32x4 &keys, int slot, int i) {
-        blds16(krsrc, __umul24(keys[i], kstride_b) + kswz[i], 0, smem + slot * TB + (4 * w + i) * 1024);
-    };
-    auto issue_v1 = [&](const u32x4 &keys, int slot, int i) {
-        blds16(vrsrc, __umul24(keys[i], vstride_b) + vswz, 0, smem + VRING + slot * TB + (4 * w + i) * 1024);
-    };
-    auto issue_k = [&](const u32x4 &keys, int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_k1(keys, slot, i);
-    };
-    auto issue_v = [&](const u32x4 &keys, int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_v1(keys, slot, i);
-    };
-
-    // ---- prologue: K(0); "iterations" -3..-1 (iteration i issues K(i+4) and V(i+2); V(-1) does not exist: V(0) goes into
-    //      its slot so that the first tile's PV -- P = 0 -- multiplies finite numbers)
-    u32x4 ir[4];   // gather keys of four tiles (entry = tile mod 4)
-    ir[0] = load_idx(0), ir[1] = load_idx(1), ir[2] = load_idx(2), ir[3] = load_idx(3);
-    clamp_idx(ir[0]), clamp_idx(ir[1]), clamp_idx(ir[2]), clamp_idx(ir[3]);
-    issue_k(ir[0], 0);
-    issue_k(ir[1], 1), issue_v(ir[0], 3);
-    issue_k(ir[2], 2), issue_v(ir[0], 0);
-    issue_k(ir[3], 3), issue_v(ir[1], 1);
-    ir[0] = load_idx(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     static_for<0, 8>([&](auto i) { lds_k<decltype(i)::value, 0>(kad[decltype(i)::value]); });
@@ -486,7 +489,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             o[I * 4 + 0] = o4[0], o[I * 4 + 1] = o4[1], o[I * 4 + 2] = o4[2], o[I * 4 + 3] = o4[3];
         });
     };
-    auto store_o = [&](int qb, const float (&o)[64], float l) __attribute__((always_inline)) {
+    // the accumulation base of a query block (INPLACE forms): this lane's 16 x 8 bytes of row qb*32 + l31
+    auto load_base = [&](int qb, u32x2 (&old)[16]) __attribute__((always_inline)) {
+        const int qrow = row0 + qb * 32 + l31;
+        const int64_t ooff = b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + 4 * hf;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32x2 z = {0u, 0u};
+            old[i] = qrow < p.Nq ? *(const u32x2 *)(p.o_in + ooff + (i >> 2) * 32 + (i & 3) * 8) : z;
+        }
+    };
+    auto store_o = [&](int qb, const float (&o)[64], float l, const u32x2 (&base)[16]) __attribute__((always_inline)) {
         // O = O^T / l; a lane holds, per d block, four groups of 4 consecutive d of query row qb*32 + l31
         const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
         const int qrow = row0 + qb * 32 + l31;
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             u32x2 out;
             if constexpr (INPLACE) {
                 // bf16 store of o_scale*result, then bf16 reduce-add into the base (csp_attn.cu:294-300)
-                const u32x2 old = *(const u32x2 *)(p.o_in + ooff + db * 32 + r4 * 8);
+                const u32x2 old = base[i];
                 const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
                 const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
                 out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
@@ -514,10 +527,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     if (nsp == 1) {
+        // the three blocks' accumulation bases are requested together, before the first accumulator is read: one memory round trip
+        // per item instead of one per block (a lone wave waits them out with nothing else to run)
+        u32x2 base[3][16] = {};
+        if constexpr (INPLACE) {
+            load_base(0, base[0]), load_base(1, base[1]), load_base(2, base[2]);
+        }
         static_for<0, 3>([&](auto qq) {
             float o[64];
             read_o(qq, o);
-            store_o(decltype(qq)::value, o, lq[decltype(qq)::value]);
+            store_o(decltype(qq)::value, o, lq[decltype(qq)::value], base[decltype(qq)::value]);
         });
         return;
     }
@@ -567,7 +586,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < 64; ++i) o[i] = o[i] * a + oth[(qb * 64 + i) * 128] * c;
         }
-        store_o(qb, o, ll);
+        u32x2 base[16] = {};
+        if constexpr (INPLACE) load_base(qb, base);
+        store_o(qb, o, ll, base);
     }
 }
 
