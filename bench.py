@@ -267,7 +267,7 @@ def pmc_traffic(op_name):
              "dense_colsum_topk_mask": ["dense_colsum_topk_mask_c3"],
              "csp_mlp_mm1_fp8": ["mm1_fp8"]}
     keys = [k + PMC_SUFFIX for k in parts.get(op_name, [])] if PMC_SUFFIX else parts.get(op_name, [])
-    for fname in ("r03o_pmc_traffic.json", "r03n_pmc_traffic.json", "r03m_pmc_traffic.json", "r03_pmc_traffic.json", "r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r03p_pmc_traffic.json", "r03o_pmc_traffic.json", "r03n_pmc_traffic.json", "r03m_pmc_traffic.json", "r03_pmc_traffic.json", "r02l_pmc_traffic.json", "r02k_pmc_traffic.json", "r02j_pmc_traffic.json", "r02h_pmc_traffic.json", "r02f_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
             continue
