@@ -1104,6 +1104,9 @@ def main():
                 "avg_launch_ms": ms,
                 "launches_in_timed_region": k["launches"], "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts, "hbm_frac_at_algorithmic_bytes": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if (hunyuan or wan) and name == "csp_128_attn":
+            roof["avg_launch_ms_covers"] = ("the operator call: csp96_kernel + its two helper launches (knorm_max_kernel over K, ~0.14 ms at "
+                                            "HunyuanVideo size, and attn_plan_kernel, ~0.05 ms); rocprof's csp96_kernel mean is that much lower")
 
     if roof and hunyuan and rank == 0 and not args.no_projections:
         # context for `frac`: what the vendor library's own bf16 GEMM sustains on THIS box, same run (every MFMA-bound kernel here runs
