@@ -81,3 +81,38 @@ def test_two_rank_line_rehearsed_on_one_gpu(mode):
     assert sum(plan["chunks"]) == (12 if mode == "heads" else 24) and plan["exchange_ms_per_head_measured"] > 0
     assert "rehearsal" in d["config"] and d["cpu_baseline"] is None and d["value"] > 0
     assert 0.0 <= d["exposed_comm"]["exposed_fraction"] <= 1.0
+
+
+def test_block_loop_with_the_fused_rowwise_pass_equals_the_torch_ops():
+    """bench.py's HunyuanBlock chain (double-stream block -> single-stream block -> double-stream block; attention replaced by a fixed
+    tensor) with the gated residual + LayerNorm + modulate as chipmunk.residual_ln_modulate -- including the hand-over of the next
+    block's LayerNorm + modulate to the previous block's closing residual -- against the same chain on torch's elementwise ops:
+    the restructured loop computes the same hidden state (bf16 rounding apart: the fused pass can land one step away, see
+    test_residual_ln_modulate_matches_the_reference_sequence)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda:0")
+    rows, hid, ffn, heads = 1024, 512, 2048, 4
+    torch.manual_seed(3)
+    blocks = [bench.HunyuanBlock(kind, dev, hid, ffn, heads) for kind in ("double", "single", "double")]
+    x0 = torch.randn(rows, hid, device=dev, dtype=torch.bfloat16)
+    attn = [torch.randn(rows, hid, device=dev, dtype=torch.bfloat16) * 0.5 for _ in blocks]
+
+    def run(fused):
+        bench.HunyuanBlock.fused_rowwise = fused
+        x, xm = x0, None
+        with torch.no_grad():
+            for i, blk in enumerate(blocks):
+                h = blk.pre(x, xm)
+                x, xm = blk.post(x, h, attn[i], blocks[i + 1].first_mod() if i + 1 < len(blocks) else None)
+        return x
+
+    try:
+        a, b = run(True), run(False)
+    finally:
+        bench.HunyuanBlock.fused_rowwise = True
+    torch.cuda.synchronize()
+    scale = b.float().abs().max().item()
+    assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -5 * scale, ((a.float() - b.float()).abs().max().item(), scale)
+    assert ((a.float() - b.float()).abs() <= 2.0 ** -7 * scale).float().mean().item() > 0.99
