@@ -10,7 +10,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_a96prof.so")
-SRC = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "capi.hip")]
+import glob
+SRC = sorted(glob.glob(os.path.join(ROOT, "chipmunk_amd", "csrc", "*.hip")))   # (not via chipmunk_amd.build: importing the package would load the product library beside this one)
 if "--build-only" in sys.argv or not os.path.exists(LIB):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DATTN96_PROF", "-o", LIB] + SRC)
@@ -41,4 +42,6 @@ names = ["wait+bar", "48 slots"]
 for w in range(2):
     n = buf[w * 8 + 7]
     per = [buf[w * 8 + i] / max(n, 1) for i in range(2)]
-    print(f"wave {w}: tiles {n}  " + "  ".join(f"{nm} {x:7.1f}" for nm, x in zip(names, per)) + f"   total {sum(per):7.1f}")
+    print(f"wave {w}: tiles {n}  " + "  ".join(f"{nm} {x:7.1f}" for nm, x in zip(names, per)) + f"   total {sum(per):7.1f}"
+          f"   | prologue (entry -> first tile) {buf[w * 8 + 2]} cycles = {buf[w * 8 + 2] / max(sum(per), 1):.1f} tiles, "
+          f"epilogue (loop end -> stores landed) {buf[w * 8 + 3]} cycles = {buf[w * 8 + 3] / max(sum(per), 1):.1f} tiles")
