@@ -73,6 +73,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5, l15 = lane & 15, lg = lane >> 4;
+#ifdef ATTN96_PROF
+    const unsigned long long t_entry_ = __builtin_amdgcn_s_memtime();
+#endif
     int wid = blockIdx.x;
     const int wid0 = wid;
     wid = p.plan[2 * wid0];
@@ -334,6 +337,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     P96_DECL;
     P96_START();
+#ifdef ATTN96_PROF
+    if (prof_on_) pacc_[2] = pt_ - t_entry_;   // prologue: kernel entry -> first tile
+#endif
     auto tile = [&](auto slc, auto nmc, int t) __attribute__((always_inline)) {
         constexpr int SL = decltype(slc)::value;
         constexpr bool NOMAX = decltype(nmc)::value != 0;   // fixed reference point: no maxima, no update / rescale
@@ -471,6 +477,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     mfma_pv<2, 2>((u32x4){vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]}, pw[2][1]);
     mfma_pv<2, 3>((u32x4){vlo[2][0], vlo[2][1], vhi[2][0], vhi[2][1]}, pw[2][1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ATTN96_PROF
+    const unsigned long long t_loop_end_ = __builtin_amdgcn_s_memtime();
+#endif
     P96_END(w, T4 + 1);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 
@@ -538,6 +547,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             read_o(qq, o);
             store_o(decltype(qq)::value, o, lq[decltype(qq)::value], base[decltype(qq)::value]);
         });
+#ifdef ATTN96_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (prof_on_ && lane == 0) g_a96_prof[w * 8 + 3] = __builtin_amdgcn_s_memtime() - t_loop_end_;   // epilogue incl. the stores landing
+#endif
         return;
     }
     // ---- key-sliced item: publish this slice's (o, m, l) -- [198 values][128 threads], coalesced -- take a ticket; the last
