@@ -19,8 +19,21 @@ for name, val in [a.split("=") for a in sys.argv[1:]]:
     _native.set_option(name, int(val))
 ref = torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts)
 torch.cuda.synchronize()
+# DET_STRESS=1: a second stream copies 4 GB tensors around the launch (the loop's index loads are consumed under a counted vmcnt with
+# LDS-DMAs behind them: DESIGN.md 4.1, "a third step was a race").  Weak as a latency stress: the gathered kernel owns every VGPR of the
+# CUs it runs on, so the copy kernels mostly run before / after it, not beside it.
+stress = os.environ.get("DET_STRESS") == "1"
+if stress:
+    side = torch.cuda.Stream()
+    big_a = torch.empty(1 << 31, dtype=torch.bfloat16, device=dev)
+    big_b = torch.empty_like(big_a)
 bad = 0
 for i in range(int(os.environ.get("RUNS", "40"))):
+    if stress:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big_b.copy_(big_a)
     o = torch.ops.chipmunk.csp_128_attn(q, k, v, inds, counts)
     torch.cuda.synchronize()
     if not torch.equal(o, ref):
