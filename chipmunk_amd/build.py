@@ -28,15 +28,42 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(path: str):
+    """Local headers a source includes (one level is all this tree has)."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith('#include "'):
+                h = line.split('"')[1]
+                for base in (CSRC, os.path.join(ROOT, "..", "include")):
+                    hp = os.path.join(base, h)
+                    if os.path.exists(hp):
+                        out.append(hp)
+    return out
+
+
 def build_hip_lib(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn64_regs.h"), os.path.join(CSRC, "attn_params.h"), os.path.join(CSRC, "attn64_util.h"), os.path.join(CSRC, "attn96_sched.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
-    if force or _newer(HIP_LIB, deps):
-        os.makedirs(LIBDIR, exist_ok=True)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs
+    """One object per source (compiled in parallel, rebuilt only when the source or a header it includes changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "..", "include", "chipmunk_hip.h")]
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + common + _includes(src)):
+            jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", obj, src])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or _newer(HIP_LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 

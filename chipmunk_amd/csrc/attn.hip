@@ -43,6 +43,8 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // workgroup 0, s_memtime at the segment boundaries of every tile, summed per segment.  Not part of the product build.
 __device__ unsigned long long g_attn_prof[8 * 8];
 #define PROF_DECL unsigned long long pt_, pacc_[7] = {0, 0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == (gridDim.x / 2)
+// absolute marks of one workgroup's life (entry, prologue issued, loop entered, loop left, epilogue done): slots 32 + wave * 8 + i
+#define PROF_ABS(i) do { if (blockIdx.x == (gridDim.x / 2) && (threadIdx.x & 63) == 0) g_attn_prof[32 + (threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
 #define PROF_END(w, ntiles) do { if (prof_on_ && lane == 0) { for (int i_ = 0; i_ < 7; ++i_) g_attn_prof[(w) * 8 + i_] = pacc_[i_]; g_attn_prof[(w) * 8 + 7] = (ntiles); } } while (0)
@@ -54,6 +56,7 @@ extern "C" int chipmunk_attn_prof_read(unsigned long long *out) {
 #define PROF_START()
 #define PROF_MARK(i)
 #define PROF_END(w, ntiles)
+#define PROF_ABS(i)
 #endif
 
 // Pin a value to this point of the program: the optimiser may neither sink its computation below nor hoist its uses above
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
+    PROF_ABS(0);
 
     int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
 
     // ---- prologue: keys of tiles 0..NST-1 synchronously, then the data of tiles 0..NST-2, each group followed by one more
     //      key DMA (the main loop reads a tile's keys one iteration before it issues the tile's data: keys run 7 ahead)
+    PROF_ABS(1);
     if (tend > tbeg) {
 #pragma unroll
         for (int T = 0; T < NST; ++T) issue_keys(tbeg + T);
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     }
 
     PROF_DECL;
+    PROF_ABS(2);
     PROF_START();
     {
         // ---- pipelined loop: PV runs ONE TILE BEHIND QK^T.  Iteration t: S(t) = K(t).Q^T, then ONE scheduling region holding
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
     PROF_END(w, tend - tbeg);
+    PROF_ABS(3);
 
     if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
@@ -660,6 +667,10 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
         }
     }
+#ifdef ATTN_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the mark is taken once the stores have left
+#endif
+    PROF_ABS(4);
 }
 
 // Work plan for ragged key counts.  HunyuanVideo's text / tail query groups keep ALL 119k keys (13x a normal group); a

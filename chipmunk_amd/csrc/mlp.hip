@@ -18,15 +18,47 @@ namespace {
 
 constexpr int BM = 128;  // rows per workgroup = one sparsity group (reference bm = 128)
 
+#ifdef MLP_PROF
+// Cycle anatomy of the GEMM k loops (tools/mlp_prof.py builds a separate library with -DMLP_PROF): s_memtime at the segment
+// boundaries of every k step, per wave of one mid-grid workgroup.  Not part of the product build.
+__device__ unsigned long long g_mlp_prof[16 * 8];
+#define MPROF_DECL unsigned long long pt_ = 0, pacc_[6] = {0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == 161
+#define MPROF_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define MPROF_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define MPROF_END(w, n) do { if (prof_on_ && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) g_mlp_prof[(w) * 8 + i_] = pacc_[i_]; g_mlp_prof[(w) * 8 + 7] = (n); } } while (0)
+extern "C" int chipmunk_mlp_prof_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_prof), sizeof(g_mlp_prof)) == hipSuccess ? 0 : 2;
+}
+#else
+#define MPROF_DECL
+#define MPROF_START()
+#define MPROF_MARK(i)
+#define MPROF_END(w, n)
+#endif
+
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// tanh-GeLU (reference csrc/common/elementwise/gelu.cuh:26-30): x*0.5*(1+tanh(u)) == x*(1 - 1/(1+exp(2u)))
+// tanh-GeLU (reference csrc/common/elementwise/gelu.cuh:26-30): x*0.5*(1+tanh(u)) == x*(1 - 1/(1+exp(2u))), u = 0.79788456*(x + 0.044715 x^3);
+// evaluated as x - x / (1 + exp2(x * (GA + GB x^2))).  The 2-wide form is the same operation sequence on v_pk_*_f32 (the epilogue
+// is VALU-bound: tools/mlp_prof.py, 18 k of a tile's 103 k cycles before this form), element-for-element the same bits.
+constexpr float GELU_A = 0.7978845608028654f * 2.0f * 1.44269504089f, GELU_B = GELU_A * 0.044715f;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack_bf16x2_v(f32x2 v) { return pack_bf16x2(v[0], v[1]); }   // v_cvt_pk_bf16_f32, RNE
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ float gelu_tanh(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(u * (2.0f * 1.44269504089f));
-    return x - x * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float t = __builtin_fmaf(x * x, GELU_B, GELU_A);
+    const float e = __builtin_amdgcn_exp2f(x * t);
+    return __builtin_fmaf(-x, __builtin_amdgcn_rcpf(e + 1.0f), x);
+}
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    const f32x2 t = __builtin_elementwise_fma(x * x, (f32x2){GELU_B, GELU_B}, (f32x2){GELU_A, GELU_A});
+    const f32x2 u = x * t;
+    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_elementwise_fma(-x, r, x);
 }
 
 template <int N>
@@ -184,26 +216,40 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         }
     };
 
+    // bf16: the bias seeds the fp32 accumulators, as in the reference (csp_mlp_mm1.cu:347-350) -- its two dependent loads (index,
+    // then bias) fly during the prologue instead of in front of the epilogue.  fp8 scales the sum first, so it starts from zero.
+    constexpr bool SEED_BIAS = !FP8;
     f32x16 acc[MT][NT4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int n4 = 0; n4 < NT4; ++n4) {
+        float seed = 0.f;
+        if constexpr (SEED_BIAS) {
+            const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
+            seed = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
+        }
 #pragma unroll
-        for (int n4 = 0; n4 < NT4; ++n4)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][n4][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[mt][n4][r] = seed;
+    }
 
     const int nkb = (int)((uint32_t)p.K * ESZ / (BK * 2));
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < nkb) issue(s, s);
     int buf = 0, nbuf = NST - 1;
+    MPROF_DECL;
+    MPROF_START();
     for (int kb = 0; kb < nkb; ++kb) {
         // tile kb must have landed; the NST-2 younger tiles may stay in flight across the barrier
         if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
         else wait_vmcnt<0>();
+        MPROF_MARK(0);
         __builtin_amdgcn_s_barrier();
+        MPROF_MARK(1);
         if (kb + NST - 1 < nkb && p.probe != 1) issue(kb + NST - 1, nbuf);
         if (kb == nkb - 1) issue_cache(nbuf);  // the stage tile kb-1 occupied is free for good
+        MPROF_MARK(2);
         if (p.probe == 2) {
             buf = buf + 1 == NST ? 0 : buf + 1;
             nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
@@ -254,9 +300,11 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        MPROF_MARK(3);
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
+    MPROF_MARK(4);
 
     if (p.probe == 4) {  // timing probe: no epilogue
         float t = 0.f;
@@ -279,48 +327,47 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         constexpr int LPO = TN * 2 / 16;  // 16-byte chunks per output row
         wait_vmcnt<0>();
         __syncthreads();  // cache block landed; every wave is done reading the last tile
+        // The output stage is plain row-major: a ds_write_b16 puts 32 consecutive columns of one row (64 contiguous bytes) per half
+        // wave, and the 16-byte read-back below walks whole rows, so neither side needs a swizzle (the cache block does: its 32 lanes
+        // of a read hit 32 rows of the [column][m] image at one m).  Two values per instruction wherever the ISA has a packed form.
 #pragma unroll
         for (int n4 = 0; n4 < NT4; ++n4) {
             const int jl = wn * (TN / 2) + n4 * 32 + (lane & 31);
-            const int j = n0 + jl;
-            const float bia = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
+            float bia = 0.f, sab = 1.f;
+            if constexpr (FP8) {
+                const int j = n0 + jl;
+                bia = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
+                sab = p.scale_a[0] * p.scale_b[0];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int ml = wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
-                    const u32x2 cv = *(const u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2);
-                    const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
-                    const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
-                    const float cc[4] = {c0, c1, c2, c3};
-                    float x[4], act[4];  // packed delta before its bf16 rounding; fp8: the new activation (bf16)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if constexpr (FP8) {
-                            // acc*scale_a*scale_b + bias -> gelu -> bf16, then a bf16 subtract (csp_mlp_mm1.py:121-133)
-                            act[e] = round_bf16(gelu_tanh(acc[mt][n4][q4 * 4 + e] * p.scale_a[0] * p.scale_b[0] + bia));
-                            x[e] = act[e] - cc[e];
-                        } else {
-                            act[e] = 0.f;
-                            x[e] = gelu_tanh(acc[mt][n4][q4 * 4 + e] + bia) - cc[e];
-                        }
+                    unsigned char *cp = Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2;
+                    const u32x2 cv = *(const u32x2 *)cp;
+                    const f32x2 c01 = {__uint_as_float(cv[0] << 16), __uint_as_float(cv[0] & 0xffff0000u)};
+                    const f32x2 c23 = {__uint_as_float(cv[1] << 16), __uint_as_float(cv[1] & 0xffff0000u)};
+                    f32x2 a01 = {acc[mt][n4][q4 * 4 + 0], acc[mt][n4][q4 * 4 + 1]}, a23 = {acc[mt][n4][q4 * 4 + 2], acc[mt][n4][q4 * 4 + 3]};
+                    uint32_t d01, d23, n01 = 0, n23 = 0;   // packed deltas as stored (bf16 pairs); the cache block's new values
+                    if constexpr (FP8) {
+                        // acc*scale_a*scale_b + bias -> gelu -> bf16, then a bf16 subtract (csp_mlp_mm1.py:121-133)
+                        const f32x2 sv = {sab, sab}, bv = {bia, bia};
+                        const uint32_t t01 = pack_bf16x2_v(gelu_tanh2(__builtin_elementwise_fma(a01, sv, bv)));
+                        const uint32_t t23 = pack_bf16x2_v(gelu_tanh2(__builtin_elementwise_fma(a23, sv, bv)));
+                        d01 = pack_bf16x2_v(unpack_bf16x2(t01) - c01), d23 = pack_bf16x2_v(unpack_bf16x2(t23) - c23);
+                        if (p.update_cache == 2) n01 = t01, n23 = t23;   // 2: cache = new activation, what the reference's Triton kernel does (csp_mlp_mm1.py:140)
+                    } else {
+                        // the bias is already in the sum (SEED_BIAS)
+                        d01 = pack_bf16x2_v(gelu_tanh2(a01) - c01), d23 = pack_bf16x2_v(gelu_tanh2(a23) - c23);
                     }
-                    float xr[4];  // the packed deltas as stored (bf16)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = ml + e;
-                        const uint16_t xb = f32_to_bf16_bits(x[e]);
-                        xr[e] = bf16_bits_to_f32(xb);
-                        *(uint16_t *)(Ot + r * (TN * 2) + (((jl >> 3) ^ (r & (LPO - 1))) << 4) + (jl & 7) * 2) = xb;
-                    }
+                    uint16_t *op = (uint16_t *)(Ot + ml * (TN * 2) + jl * 2);
+                    op[0] = (uint16_t)d01, op[TN] = (uint16_t)(d01 >> 16), op[2 * TN] = (uint16_t)d23, op[3 * TN] = (uint16_t)(d23 >> 16);
                     if (p.update_cache) {
-                        // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98);
-                        // 2: cache = new activation, what the reference's fp8 Triton kernel does (csp_mlp_mm1.py:140)
-                        const bool literal = FP8 && p.update_cache == 2;
-                        u32x2 nc;
-                        nc[0] = literal ? pack_bf16x2(act[0], act[1]) : pack_bf16x2(c0 + xr[0], c1 + xr[1]);
-                        nc[1] = literal ? pack_bf16x2(act[2], act[3]) : pack_bf16x2(c2 + xr[2], c3 + xr[3]);
-                        *(u32x2 *)(Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2) = nc;
+                        // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
+                        if (!(FP8 && p.update_cache == 2))
+                            n01 = pack_bf16x2_v(c01 + unpack_bf16x2(d01)), n23 = pack_bf16x2_v(c23 + unpack_bf16x2(d23));
+                        *(u32x2 *)cp = (u32x2){n01, n23};
                     }
                 }
             }
@@ -330,7 +377,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
         for (int i = 0; i < O_INST; ++i) {
             const int r = (w * O_INST + i) * (64 / LPO) + lane / LPO, ch = lane % LPO;
-            const u32x4 v = *(const u32x4 *)(Ot + r * (TN * 2) + ((ch ^ (r & (LPO - 1))) << 4));
+            const u32x4 v = *(const u32x4 *)(Ot + r * (TN * 2) + (ch << 4));
             const int j = n0 + ch * 8;
             uint16_t *cp = p.c + (int64_t)(g * BM + m_off + r) * p.F + j;
             if (j + 8 <= cnt && (p.F & 7) == 0) {
@@ -355,7 +402,6 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
             const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
             const bool live = j < cnt;
             const int col = live ? idxg[j] : 0;
-            const float bia = bf16_bits_to_f32(p.bias[col]);
             const uint16_t *crow = p.cache + (int64_t)col * p.M;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -365,10 +411,10 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                     const u32x2 cv = *(const u32x2 *)(crow + m);
                     const float c0 = __uint_as_float(cv[0] << 16), c1 = __uint_as_float(cv[0] & 0xffff0000u);
                     const float c2 = __uint_as_float(cv[1] << 16), c3 = __uint_as_float(cv[1] & 0xffff0000u);
-                    const float x0 = gelu_tanh(acc[mt][n4][q4 * 4 + 0] + bia) - c0;
-                    const float x1 = gelu_tanh(acc[mt][n4][q4 * 4 + 1] + bia) - c1;
-                    const float x2 = gelu_tanh(acc[mt][n4][q4 * 4 + 2] + bia) - c2;
-                    const float x3 = gelu_tanh(acc[mt][n4][q4 * 4 + 3] + bia) - c3;
+                    const float x0 = gelu_tanh(acc[mt][n4][q4 * 4 + 0]) - c0;   // (bias already in the sum)
+                    const float x1 = gelu_tanh(acc[mt][n4][q4 * 4 + 1]) - c1;
+                    const float x2 = gelu_tanh(acc[mt][n4][q4 * 4 + 2]) - c2;
+                    const float x3 = gelu_tanh(acc[mt][n4][q4 * 4 + 3]) - c3;
                     if (live) {
                         uint16_t *cp = p.c + (int64_t)m * p.F + j;
                         cp[0] = f32_to_bf16_bits(x0);
@@ -380,6 +426,11 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
             }
         }
     }
+#ifdef MLP_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MPROF_MARK(5);   // epilogue (mark 4 = loop exit edge)
+    MPROF_END(w, nkb);
 }
 
 template <int BN, int BK, int NST, int WPS, bool FP8 = false>
@@ -499,14 +550,19 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
     if (NST - 1 < nkb) load_keys(NST - 1);
     const int li = lane & 15, grp = lane >> 4;
     int buf = 0, nbuf = NST - 1;
+    MPROF_DECL;
+    MPROF_START();
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb + NST - 1 <= nkb) wait_vmcnt<(NST - 2) * (A_INST + B_INST)>();
         else wait_vmcnt<0>();
+        MPROF_MARK(0);
         __builtin_amdgcn_s_barrier();
+        MPROF_MARK(1);
         if (kb + NST - 1 < nkb) {
             issue(kb + NST - 1, nbuf);
             if (kb + NST < nkb) load_keys(kb + NST);  // (moving these behind the MFMAs measured 15 % slower)
         }
+        MPROF_MARK(2);
         const unsigned char *At = smem + buf * STAGE;
         const unsigned char *Bt = At + A_TILE;
         constexpr int KK = BK / 16;
@@ -543,9 +599,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
                     acc[n4][mt] = mfma32(wf[kk & 1][n4], pf[kk & 1][mt], acc[n4][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        MPROF_MARK(3);
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
+    MPROF_END(w, nkb);
 
     if (p.probe == 4) {  // timing probe: no epilogue
         float t = 0.f;
@@ -720,6 +778,8 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
         case 12: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
         case 13: return launch_mm2_variant<256, 32, 4, 1, 8>(p, s);
         case 14: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // the 4-wave form of the default
+        case 15: return launch_mm2_variant<512, 32, 4, 2, 8>(p, s);  // 128 x 512 tiles, one workgroup per CU, wave tile 64 x 128
+        case 16: return launch_mm2_variant<512, 32, 3, 2, 8>(p, s);
         // 8 waves (2 x 4, 64 x 64 per wave, 4 waves per SIMD) x 2 workgroups per CU: equal to the 4-wave form in
         // isolation, 2 % faster inside the bench loop (A/B on one box: 170.5 -> 167.3 us, twice)
         default: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);

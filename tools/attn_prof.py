@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--heads", type=int, default=24)
     ap.add_argument("--sparse", type=int, default=0, help="gathered launch with this many keys per group (0 = dense)")
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--inplace", action="store_true", help="sparse: chipmunk_csp_attn (in-place accumulate, the FLUX form)")
     ap.add_argument("--pp", action="store_true", help="the ping-pong kernel (segments: wait+barrier, DMA issue, M phase, V phase)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
     args = ap.parse_args()
@@ -56,7 +57,9 @@ def main():
         counts = torch.full((1, H, G), args.sparse, dtype=torch.int32, device=dev)
 
     def launch():
-        if args.sparse:
+        if args.sparse and args.inplace:
+            rc = lib.chipmunk_csp_attn(P(q), P(k), P(v), P(o), st, st, st, st, P(inds), P(counts), 1, H, N, N, G * 192, 1, None)
+        elif args.sparse:
             rc = lib.chipmunk_csp_128_attn(P(q), P(k), P(v), P(o), P(inds), P(counts), 1, H, N, N, G * 192, None)
         else:
             rc = lib.chipmunk_dense_attn(P(q), P(k), P(v), st, st, st, P(o), P(l), 1, H, N, N, None)
@@ -83,6 +86,11 @@ def main():
             continue
         seg = [buf[w * 8 + i] / nt for i in range(7)]
         print(f"  wave {w}: {nt} tiles, " + ", ".join(f"{n} {c:.0f}" for n, c in zip(names, seg) if n != "-") + f"  | total {sum(seg):.0f} ticks/tile")
+    if not args.pp:
+        for w in range(4):
+            a = [buf[32 + w * 8 + i] for i in range(5)]
+            if a[4] > a[0] > 0:
+                print(f"  wave {w} life (s_memtime ticks): entry->prologue start {a[1]-a[0]}, prologue {a[2]-a[1]}, loop {a[3]-a[2]}, epilogue {a[4]-a[3]}, total {a[4]-a[0]}")
 
 
 if __name__ == "__main__":

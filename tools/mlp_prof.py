@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Cycle anatomy of the column-sparse GEMM k loops: builds chipmunk_amd/csrc with -DMLP_PROF into tools/bin/libchipmunk_mlpprof.so
+(s_memtime at the segment boundaries of every k step, per wave of one first-round workgroup) and prints per wave the ticks per k step
+spent in: vmcnt wait, barrier, DMA issue (+ key loads), fragment reads + MFMAs; for GEMM1 also the loop exit and the epilogue.
+usage: python tools/mlp_prof.py [mm1|mm1s|mm2] [--opt name=value ...]"""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_mlpprof.so")
+
+
+def build():
+    src = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "rowwise.hip", "capi.hip")]
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMLP_PROF", "-o", LIB] + src)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="mm1")
+    ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--layers", type=int, default=8)
+    args = ap.parse_args()
+    if args.build_only or not os.path.exists(LIB):
+        build()
+        if args.build_only:
+            return
+    import torch
+    lib = ctypes.CDLL(LIB)
+    for o_ in args.opt:
+        name, val = o_.split("=")
+        assert lib.chipmunk_set_option(name.encode(), int(val)) == 0
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    M, K, F, keep = 4352, 3072, 12288, 4096
+    G = M // 128
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
+    bias = torch.zeros(F, device=dev, dtype=torch.bfloat16)
+    sets = []
+    for _ in range(args.layers):
+        w1 = (torch.randn(F, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        cache = torch.randn(F, M, device=dev, dtype=torch.bfloat16, generator=g)
+        packed = torch.randn(M, F, device=dev, dtype=torch.bfloat16, generator=g) * 0.1
+        w2t = (torch.randn(F, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        out = torch.zeros(M, K, device=dev, dtype=torch.bfloat16)
+        sets.append((w1, cache, packed, w2t, out))
+    inds = torch.stack([torch.cat([torch.randperm(F, device=dev, generator=g)[:keep].sort().values,
+                                   torch.zeros(F - keep, dtype=torch.int64, device=dev)]) for _ in range(G)]).to(torch.int32).contiguous()
+    counts = torch.full((G,), keep, dtype=torch.int32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = {"i": 0}
+
+    def launch():
+        st["i"] = (st["i"] + 1) % len(sets)
+        w1, cache, packed, w2t, out = sets[st["i"]]
+        if args.what == "mm1":
+            rc = lib.chipmunk_csp_mlp_mm1(P(a), P(w1), P(packed), P(bias), P(cache), P(inds), P(counts), M, K, F, None)
+        elif args.what == "mm1s":
+            rc = lib.chipmunk_csp_mlp_mm1_scatter(P(a), P(w1), P(packed), P(bias), P(cache), P(inds), P(counts), M, K, F, None)
+        else:
+            rc = lib.chipmunk_csp_mlp_mm2(P(packed), P(w2t), P(out), P(inds), P(counts), M, F, K, None)
+        assert rc == 0
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{args.what}: {e0.elapsed_time(e1) * 100:.1f} us per launch (instrumented build)")
+    buf = (ctypes.c_uint64 * 128)()
+    assert lib.chipmunk_mlp_prof_read(buf) == 0
+    names = ["vmcnt wait", "barrier", "dma issue", "frags+mfma", "loop exit", "epilogue"]
+    for w in range(16):
+        n = buf[w * 8 + 7]
+        if not n:
+            continue
+        seg = [buf[w * 8 + i] for i in range(6)]
+        loop = sum(seg[:4])
+        print(f"  wave {w}: {n} k steps, per step: " + ", ".join(f"{nm} {c / n:.0f}" for nm, c in zip(names[:4], seg[:4])) +
+              f" | loop {loop} ticks = {loop / n:.0f}/step; loop exit {seg[4]}, epilogue {seg[5]}")
+
+
+if __name__ == "__main__":
+    main()

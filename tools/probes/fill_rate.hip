@@ -5,6 +5,7 @@
 //   mode 1: buffer_load_dwordx4 ... lds (LDS-DMA, SGPR base + 32-bit per-lane offset)
 //   mode 2: global_load_dwordx4 -> VGPR -> ds_write_b128 (one step of register prefetch)
 //   mode 3: buffer_load_dwordx4 -> VGPR -> ds_write_b128
+//   mode 4: buffer_load_dwordx4 -> VGPR only (the L1 -> register path alone)
 // usage: fill_rate [mfma_per_step]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256, 2) void fill(const unsigned char *mat, const i
         };
         auto lwrite = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(u32x4 *)(smem + buf * STAGE + (w * 8 + i) * 1024 + lane * 16) = regs[i];
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (MODE == 4) { if (regs[i][0] == 0x12345u && regs[i][3] == 7u) sink[1] = 1.f; }   // mode 4: loads only, no LDS write
+                else *(u32x4 *)(smem + buf * STAGE + (w * 8 + i) * 1024 + lane * 16) = regs[i];
+            }
         };
         gload(0);
         lwrite(0);
@@ -181,14 +185,14 @@ int main(int argc, char **argv) {
         free(hm);
     }
     hipMalloc(&idx, nrows * 4);
-    hipMalloc(&sink, 4);
+    hipMalloc(&sink, 8);
     int *h = (int *)malloc(nrows * 4);
     srand(1);
     for (int i = 0; i < nrows; ++i) h[i] = rand() % nrows;
     hipMemcpy(idx, h, nrows * 4, hipMemcpyHostToDevice);
     const int nwg = 1024;
 #define RUN(M, N, F) run<M, N, F>("mode " #M " NST " #N " mfma/step " #F, mat, idx, nrows, sink, nwg)
-    RUN(0, 2, 0); RUN(1, 2, 0); RUN(2, 2, 0); RUN(3, 2, 0);
+    RUN(0, 2, 0); RUN(1, 2, 0); RUN(2, 2, 0); RUN(3, 2, 0); RUN(4, 2, 0);
     RUN(0, 3, 0); RUN(1, 3, 0);
     RUN(0, 2, 16); RUN(1, 2, 16); RUN(2, 2, 16); RUN(3, 2, 16);
     RUN(0, 3, 16); RUN(1, 3, 16);
