@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
     int sp = 0, nsp = 1, slot0 = 0, tix = 0, wid = wid0;
     if (!CSONLY && p.plan) {
-        wid = p.plan[2 * wid0];
+        const u32x2 entry = *(const u32x2 *)(p.plan + 2 * wid0);   // (one round trip, not two)
+        wid = (int)entry[0];
         if (wid < 0) return;
-        const int meta = p.plan[2 * wid0 + 1];
+        const int meta = (int)entry[1];
         sp = meta & 0xff, nsp = (meta >> 8) & 0xff;
         slot0 = tix = meta >> 16;
     } else if (!CSONLY && p.nsplit > 1 && wid0 >= p.split_full) {
@@ -140,21 +141,32 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int bh = wid / p.G, g = wid - bh * p.G;
     const int b = bh / p.H, h = bh - b * p.H;
 
-    const int count = GATHER ? p.counts[(int64_t)bh * p.G + g] : p.Nk;
-    // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
-    const int valid = count < p.Nk ? count : p.Nk;
-    const int ntiles = (valid + KVT - 1) / KVT;
-    if (!CSONLY && nsp > 1 && !p.plan) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
-        const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
-        nsp = nsp < cap ? nsp : cap;
-        if (sp >= nsp) return;
-    }
-    const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
+    // The item's key count is REQUESTED here and first used below the Q loads: count, the first key tiles' indices and the Q rows make
+    // one memory round trip together instead of three in a row (tools/attn_prof.py: 7 k + 9 k cycles of a FLUX item's 114 k passed
+    // before its first tile).
+    int count_v = GATHER ? p.counts[(int64_t)bh * p.G + g] : p.Nk;
     const IndexRow irow = GATHER ? index_row(p, (int64_t)bh * p.G + g) : IndexRow{nullptr, 0};
     const int32_t *idx = irow.ptr;
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
     const int row0 = g * QG + w * QW;
+    // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
+    auto issue_keys = [&](int T) {
+        if constexpr (GATHER) {
+            if (w == 0) {
+                int pos = T * KVT + lane;
+                pos = pos < irow.width ? pos : irow.width - 1;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T & (KRING - 1)) * 64), 4, 0, 0);
+            }
+        }
+    };
+    // an unsliced item starts at key tile 0 whatever its count: the first key tiles' indices are requested before anything else, so
+    // that their round trip runs beside the Q rows' (it used to start after the Q loads had been issued: one more serial round trip)
+    const bool early_keys = GATHER && !CSONLY && sp == 0 && irow.width > 0;
+    if (early_keys) {
+#pragma unroll
+        for (int T = 0; T < NST; ++T) issue_keys(T);
+    }
     const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
     const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;  // row strides in bytes
 
@@ -178,6 +190,23 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         }
     }
 
+    if constexpr (GATHER) {
+        // vmcnt(0), not a counted wait: index DMAs went out behind this register load, and an LDS-DMA may retire before an older
+        // register load; the operand pins every use of the count below this point
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(count_v)::"memory");
+        count_v = __builtin_amdgcn_readfirstlane(count_v);
+    }
+    const int count = count_v;
+    // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
+    const int valid = count < p.Nk ? count : p.Nk;
+    const int ntiles = (valid + KVT - 1) / KVT;
+    if (!CSONLY && nsp > 1 && !p.plan) {  // every workgroup of the item derives the same effective split: at least 4 key tiles per slice
+        const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
+        nsp = nsp < cap ? nsp : cap;
+        if (sp >= nsp) return;
+    }
+    const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
+
     f32x4 cs_off[3];  // CSONLY: log2(prev_l) of query rows qb*16 + lg*4 + 0..3 (that pass computes S, not S^T)
     if constexpr (CSONLY) {
 #pragma unroll
@@ -192,16 +221,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         for (int i = tid; i < 2 * 2 * 4 * KVT; i += 256) cs_acc[i] = 0.f;
     }
 
-    // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
-    auto issue_keys = [&](int T) {
-        if constexpr (GATHER) {
-            if (w == 0) {
-                int pos = T * KVT + lane;
-                pos = pos < irow.width ? pos : irow.width - 1;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(idx + pos), LDS_PTR(key_ring + (T & (KRING - 1)) * 64), 4, 0, 0);
-            }
-        }
-    };
     // every wave stages rows (2w+i)*4 + lg, i = 0..1, of the K tile and of the V tile: 4 DMA instructions per wave
     static_assert((NST & (NST - 1)) == 0 && (KRING & (KRING - 1)) == 0, "ring depths addressed by masks");
     // the gather key of row (2w+i)*4 + lg of tile T, clamped into the key range (memory safety for malformed indices)
@@ -243,8 +262,10 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     //      key DMA (the main loop reads a tile's keys one iteration before it issues the tile's data: keys run 7 ahead)
     PROF_ABS(1);
     if (tend > tbeg) {
+        if (!early_keys) {
 #pragma unroll
-        for (int T = 0; T < NST; ++T) issue_keys(tbeg + T);
+            for (int T = 0; T < NST; ++T) issue_keys(tbeg + T);
+        }
         wait_vmcnt<0>();
         __syncthreads();
 #pragma unroll
@@ -327,6 +348,9 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         return;
     }
 
+    // accumulate forms of an unsplit item with work to do: the epilogue's base rows are fetched ahead of the drain tile
+    const bool early_base = INPLACE && nsp == 1 && tend > tbeg;
+    u32x4 base[INPLACE ? QW * 256 / 1024 : 1];
     PROF_DECL;
     PROF_ABS(2);
     PROF_START();
@@ -565,6 +589,17 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 }
                 PROF_MARK(4);
             }
+            // accumulate forms: the base rows in the epilogue's layout (12 x 16 bytes per lane), requested before the drain tile
+            if constexpr (INPLACE) {
+                if (early_base) {
+#pragma unroll
+                    for (int i = 0; i < QW * 256 / 1024; ++i) {
+                        const int qrow = row0 + i * 4 + (lane >> 4);
+                        base[i] = (u32x4){0u, 0u, 0u, 0u};
+                        if (qrow < p.Nq) base[i] = *(const u32x4 *)(p.o_in + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + (lane & 15) * 8);
+                    }
+                }
+            }
             pv_mfmas(tend - 1);
         }
     }
@@ -625,47 +660,53 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
         }
     }
-    // ---- epilogue: O = O^T / l ; lane holds 4 consecutive d of one query row per (qb, db)
+    // ---- epilogue: O = O^T / l.  A lane holds 4 consecutive d (8 bytes) of one query row per (qb, db): stored as they stand that is
+    //      24 eight-byte accesses per lane, each instruction touching 16 rows x 32 bytes (and as many loads for the accumulate forms):
+    //      the store tail was 15.8 k of a FLUX item's 114 k cycles (tools/attn_prof.py).  The wave's 48 x 128 bf16 results go through
+    //      its own 12 KiB of the (now idle) K/V rings instead -- 8-byte writes, chunk index XOR row so that the 16 lanes of a write land on
+    //      16 different chunks -- and leave as 12 whole-row 16-byte accesses per lane (4 rows = 1 KiB per instruction); the accumulation
+    //      base is fetched in that same layout BEFORE the drain tile when this workgroup is sure to run the epilogue.
+    constexpr int EP_I = QW * 256 / 1024;   // 16-byte pieces per lane: 12
+    unsigned char *stage = smem + w * (QW * 256);
+    const int er0 = lane >> 4, ech = lane & 15;
+    auto ep_row = [&](int i) { return i * 4 + er0; };   // wave-local row of piece i
+    const int64_t obase = b * p.os[0] + h * p.os[1];
+    __syncthreads();   // every wave is done with the rings
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
         const float l = sum_across_rows(lsum[qb]);
-        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
-        const int qrow = row0 + qb * 16 + li;
-        if (qrow >= p.Nq) continue;
-        const int64_t ooff = b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + lg * 4;
-        uint16_t *op = p.o + ooff;
-        const uint16_t *oin = INPLACE ? p.o_in + ooff : nullptr;
-        if (INPLACE && ntiles == 0) {  // nothing to add: in place leaves o alone, out of place copies the base
-            if (oin != op) {
-#pragma unroll
-                for (int db = 0; db < 8; ++db) *(u32x2 *)(op + db * 16) = *(const u32x2 *)(oin + db * 16);
-            }
-            continue;
-        }
+        const float inv = (l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f) * (INPLACE ? p.o_scale : 1.f);   // o_scale = +-1: exact
+        const int r = qb * 16 + li;
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
-            float x0 = o[qb][db][0] * inv, x1 = o[qb][db][1] * inv, x2 = o[qb][db][2] * inv, x3 = o[qb][db][3] * inv;
-            u32x2 out;
-            if constexpr (INPLACE) {
-                // bf16 store of o_scale*result, then bf16 reduce-add into o (csp_attn.cu:294-300)
-                u32x2 old = {0u, 0u};
-                if (!(p.probe & 4)) old = *(const u32x2 *)(oin + db * 16);
-                const float a0 = round_bf16(x0 * p.o_scale), a1 = round_bf16(x1 * p.o_scale);
-                const float a2 = round_bf16(x2 * p.o_scale), a3 = round_bf16(x3 * p.o_scale);
-                out[0] = pack_bf16x2(__uint_as_float(old[0] << 16) + a0, __uint_as_float(old[0] & 0xffff0000u) + a1);
-                out[1] = pack_bf16x2(__uint_as_float(old[1] << 16) + a2, __uint_as_float(old[1] & 0xffff0000u) + a3);
-            } else {
-                out[0] = pack_bf16x2(x0, x1);
-                out[1] = pack_bf16x2(x2, x3);
-            }
-            if (!(p.probe & 16) || out[0] == 0x12345678u) *(u32x2 *)(op + db * 16) = out;
+            // bf16(o_scale * result): what the reference stores before its bf16 reduce-add (csp_attn.cu:294-300)
+            const u32x2 out = {pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv), pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv)};
+            *(u32x2 *)(stage + r * 256 + (((db * 2 + (lg >> 1)) ^ (r & 15)) << 4) + (lg & 1) * 8) = out;
         }
         if constexpr (WRITE_L) {
             // l = 1 / (exp2(m*c) * norm) = 1 / sum_j exp(s_ij / sqrt(D))   (dense_attn.cu:225-227)
-            if (lg == 0) {
-                p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+            const int qrow = row0 + r;
+            if (lg == 0 && qrow < p.Nq) p.l_out[(int64_t)bh * p.Nq + qrow] = 1.0f / (__builtin_amdgcn_exp2f(m[qb] * SCALE_LOG2E) * l);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EP_I; ++i) {
+        const int r = ep_row(i), qrow = row0 + r;
+        if (qrow >= p.Nq) continue;
+        const int64_t off = obase + (int64_t)qrow * p.os[2] + ech * 8;
+        u32x4 v = *(const u32x4 *)(stage + r * 256 + ((ech ^ (r & 15)) << 4));
+        if constexpr (INPLACE) {
+            const u32x4 old = early_base ? base[i] : *(const u32x4 *)(p.o_in + off);
+            if (ntiles == 0) {
+                v = old;   // nothing to add: in place leaves o as it is, out of place copies the base
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack_bf16x2(__uint_as_float(old[e] << 16) + __uint_as_float(v[e] << 16),
+                                       __uint_as_float(old[e] & 0xffff0000u) + __uint_as_float(v[e] & 0xffff0000u));
             }
         }
+        *(u32x4 *)(p.o + off) = v;
     }
 #ifdef ATTN_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the mark is taken once the stores have left

@@ -25,6 +25,7 @@ __device__ unsigned long long g_mlp_prof[16 * 8];
 #define MPROF_DECL unsigned long long pt_ = 0, pacc_[6] = {0, 0, 0, 0, 0, 0}; const bool prof_on_ = blockIdx.x == 161
 #define MPROF_START() do { if (prof_on_) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
 #define MPROF_MARK(i) do { if (prof_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define MPROF_ABS(i) do { if (blockIdx.x == 161 && (threadIdx.x & 63) == 0) g_mlp_prof[96 + (threadIdx.x >> 6) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MPROF_END(w, n) do { if (prof_on_ && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) g_mlp_prof[(w) * 8 + i_] = pacc_[i_]; g_mlp_prof[(w) * 8 + 7] = (n); } } while (0)
 extern "C" int chipmunk_mlp_prof_read(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_prof), sizeof(g_mlp_prof)) == hipSuccess ? 0 : 2;
@@ -34,6 +35,7 @@ extern "C" int chipmunk_mlp_prof_read(unsigned long long *out) {
 #define MPROF_START()
 #define MPROF_MARK(i)
 #define MPROF_END(w, n)
+#define MPROF_ABS(i)
 #endif
 
 
@@ -219,14 +221,14 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     // bf16: the bias seeds the fp32 accumulators, as in the reference (csp_mlp_mm1.cu:347-350) -- its two dependent loads (index,
     // then bias) fly during the prologue instead of in front of the epilogue.  fp8 scales the sum first, so it starts from zero.
     constexpr bool SEED_BIAS = !FP8;
+    float bias_v[NT4], sab = 1.f;   // loaded here for both forms: in front of the epilogue the two round trips would be exposed
+    if constexpr (FP8) sab = p.scale_a[0] * p.scale_b[0];
     f32x16 acc[MT][NT4];
 #pragma unroll
     for (int n4 = 0; n4 < NT4; ++n4) {
-        float seed = 0.f;
-        if constexpr (SEED_BIAS) {
-            const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
-            seed = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
-        }
+        const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
+        bias_v[n4] = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
+        const float seed = SEED_BIAS ? bias_v[n4] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -239,6 +241,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         if (s < nkb) issue(s, s);
     int buf = 0, nbuf = NST - 1;
     MPROF_DECL;
+    MPROF_ABS(1);
     MPROF_START();
     for (int kb = 0; kb < nkb; ++kb) {
         // tile kb must have landed; the NST-2 younger tiles may stay in flight across the barrier
@@ -333,12 +336,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
         for (int n4 = 0; n4 < NT4; ++n4) {
             const int jl = wn * (TN / 2) + n4 * 32 + (lane & 31);
-            float bia = 0.f, sab = 1.f;
-            if constexpr (FP8) {
-                const int j = n0 + jl;
-                bia = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
-                sab = p.scale_a[0] * p.scale_b[0];
-            }
+            const float bia = bias_v[n4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -429,6 +427,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #ifdef MLP_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+    MPROF_ABS(2);
     MPROF_MARK(5);   // epilogue (mark 4 = loop exit edge)
     MPROF_END(w, nkb);
 }
@@ -436,6 +435,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 template <int BN, int BK, int NST, int WPS, bool FP8 = false>
 __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MPROF_ABS(0);
     constexpr int NSUB = 2 * (BN / 64);  // 64 x 64 sub-tiles per tile
     const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR, p.slots_per_xcd, NSUB);
     if (!tm.live) return;

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--wan", action="store_true", help="the Wan2.1 shape (M 32768, K 1536, F 8960, keep 2688); mm1 only: fp8 with --fp8")
+    ap.add_argument("--fp8", action="store_true")
     args = ap.parse_args()
     if args.build_only or not os.path.exists(LIB):
         build()
@@ -39,6 +41,9 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     M, K, F, keep = 4352, 3072, 12288, 4096
+    if args.wan:
+        M, K, F, keep = 32768, 1536, 8960, 2688
+        args.layers = min(args.layers, 2)
     G = M // 128
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
     bias = torch.zeros(F, device=dev, dtype=torch.bfloat16)
@@ -55,11 +60,18 @@ def main():
     counts = torch.full((G,), keep, dtype=torch.int32, device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = {"i": 0}
+    if args.fp8:
+        a8 = (a.float() * 16).clamp(-448, 448).to(torch.float8_e4m3fn)
+        w8 = [(s_[0].float() * 512).clamp(-448, 448).to(torch.float8_e4m3fn) for s_ in sets]
+        sa, sb = torch.tensor([1 / 16.0], device=dev), torch.tensor([1 / 512.0], device=dev)
 
     def launch():
         st["i"] = (st["i"] + 1) % len(sets)
         w1, cache, packed, w2t, out = sets[st["i"]]
-        if args.what == "mm1":
+        if args.fp8:
+            rc = lib.chipmunk_csp_mlp_mm1_fp8(P(a8), P(w8[st["i"]]), P(packed), P(bias), P(cache), P(inds), P(counts), P(sa), P(sb), M, K, F,
+                                              2 if args.what == "mm1s" else 0, None)
+        elif args.what == "mm1":
             rc = lib.chipmunk_csp_mlp_mm1(P(a), P(w1), P(packed), P(bias), P(cache), P(inds), P(counts), M, K, F, None)
         elif args.what == "mm1s":
             rc = lib.chipmunk_csp_mlp_mm1_scatter(P(a), P(w1), P(packed), P(bias), P(cache), P(inds), P(counts), M, K, F, None)
@@ -79,6 +91,10 @@ def main():
     buf = (ctypes.c_uint64 * 128)()
     assert lib.chipmunk_mlp_prof_read(buf) == 0
     names = ["vmcnt wait", "barrier", "dma issue", "frags+mfma", "loop exit", "epilogue"]
+    for w in range(4):
+        a0, a1, a2 = (buf[96 + w * 4 + i] for i in range(3))
+        if a2 > a0 > 0:
+            print(f"  wave {w} life: entry -> loop {a1 - a0}, loop {a2 - a1 - 0} incl. epilogue, total {a2 - a0}")
     for w in range(16):
         n = buf[w * 8 + 7]
         if not n:
