@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void knorm_max_kernel(const uint16_t *k, const
     const uint16_t *kb = k + b * ks0 + h * ks1;
     const int grp = threadIdx.x >> 4, li = threadIdx.x & 15;
     float best = 0.f;
+#pragma unroll 4
     for (int row = blockIdx.x * 16 + grp; row < Nk; row += gridDim.x * 16) {
         const u32x4 v = *(const u32x4 *)(kb + (int64_t)row * ks2 + li * 8);
         float ss = 0.f;
@@ -1002,7 +1003,7 @@ const float *chipmunk_knorm_max(const uint16_t *k, const int64_t ks[3], int B, i
     if (!sc) return nullptr;
     float *km = (float *)(sc + (32 << 10));
     if (hipMemsetAsync(km, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(knorm_max_kernel, dim3(Nk >= 16384 ? 64 : 8, B * H), dim3(256), 0, stream, k, ks[0], ks[1], ks[2], H, Nk, km);
+    hipLaunchKernelGGL(knorm_max_kernel, dim3(Nk >= 4096 ? 64 : 8, B * H), dim3(256), 0, stream, k, ks[0], ks[1], ks[2], H, Nk, km);
     return km;
 }
 

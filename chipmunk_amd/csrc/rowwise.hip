@@ -107,6 +107,44 @@ void launch_rlm(const void *x, const void *y, const void *gate, const void *shif
                            (const uint16_t *)shift, (const uint16_t *)scale, nullptr, (uint16_t *)xm, rows, C, eps);
 }
 
+
+// Mean over consecutive blocks of `mbm` rows: [R, C] -> [R / mbm, C] bf16 (reference modules/mlp.py:11-16, `block_mean`, the first
+// operation of every sparse MLP step; torch's reshape + mean kernel reads the 27 MB of a FLUX layer's input in 17 us).  One workgroup
+// = (block, 512 columns): the four waves take a quarter of the block's rows each, a lane 8 columns (16 bytes) of every row; fp32
+// sums in row order, the four partial sums added in wave order, one rounding to bf16.  HBM-bound: R * C * 2 bytes.
+__global__ __launch_bounds__(256) void block_mean_kernel(const uint16_t *x, uint16_t *out, int C, int mbm) {
+    __shared__ float part[3][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    const int64_t blk = blockIdx.y;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const int per = mbm / 4;
+        const uint16_t *src = x + (blk * mbm + (int64_t)w * per) * C + c;
+#pragma unroll 8
+        for (int r = 0; r < per; ++r) {
+            const u32x4 v = *(const u32x4 *)(src + (int64_t)r * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[2 * e] += __uint_as_float(v[e] << 16), acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[w - 1][lane][e] = acc[e];
+    }
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const float inv = 1.0f / (float)mbm;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = ((acc[2 * e] + part[0][lane][2 * e]) + part[1][lane][2 * e]) + part[2][lane][2 * e];
+            const float b = ((acc[2 * e + 1] + part[0][lane][2 * e + 1]) + part[1][lane][2 * e + 1]) + part[2][lane][2 * e + 1];
+            o[e] = pack_bf16x2(a * inv, b * inv);
+        }
+        *(u32x4 *)(out + blk * C + c) = o;
+    }
+}
 }  // namespace
 
 extern "C" int chipmunk_residual_ln_modulate(const void *x, const void *y, const void *gate, const void *shift, const void *scale,
@@ -127,6 +165,17 @@ extern "C" int chipmunk_residual_ln_modulate(const void *x, const void *y, const
     else if (nv <= 6) launch_rlm<6>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
     else if (nv <= 10) launch_rlm<10>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
     else launch_rlm<16>(x, y, gate, shift, scale, x_out, xm, rows, cols, e, s);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}
+
+extern "C" int chipmunk_block_mean(const void *x, void *out, int64_t rows, int C, int mbm, void *stream) {
+    CM_CHECK(x && out, "block_mean: null tensor pointer");
+    CM_CHECK(mbm > 0 && mbm % 4 == 0 && rows > 0 && rows % mbm == 0, "block_mean: rows (%lld) must be a positive multiple of mbm (%d), mbm a multiple of 4",
+             (long long)rows, mbm);
+    CM_CHECK(C > 0 && C % 8 == 0 && rows / mbm < 65536, "block_mean: C must be a positive multiple of 8 and rows / mbm < 65536");
+    hipLaunchKernelGGL(block_mean_kernel, dim3((C + 511) / 512, (unsigned)(rows / mbm)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)x, (uint16_t *)out, C, mbm);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

@@ -521,6 +521,18 @@ at::Tensor transpose_last2(at::Tensor x) {
     return out;
 }
 
+// [b, n, c] -> [b, n / mbm, c] mean over consecutive row blocks (reference modules/mlp.py:11-16) in one HBM-rate kernel, bf16
+at::Tensor block_mean(at::Tensor x, int64_t mbm) {
+    CHECK_DEV(x);
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kBFloat16, "block_mean: need a [b, n, c] bfloat16 tensor");
+    TORCH_CHECK(mbm > 0 && x.size(1) % mbm == 0, "block_mean: n must be a multiple of mbm");
+    x = x.contiguous();
+    c10::DeviceGuard guard(x.device());
+    at::Tensor out = at::empty({x.size(0), x.size(1) / mbm, x.size(2)}, x.options());
+    check(chipmunk_block_mean(x.data_ptr(), out.data_ptr(), x.size(0) * x.size(1), (int)x.size(2), (int)mbm, cur_stream(x)), "block_mean");
+    return out;
+}
+
 // ascending-order variant of (packed_)mask_to_indices (same set / counts / padding; see chipmunk_hip.h)
 std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef shape, int64_t multiple_of,
                                                int64_t pad_to_multiple_of) {
@@ -744,6 +756,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("csp_attn_out_ragged(Tensor q, Tensor k, Tensor v, Tensor o_in, Tensor indices, Tensor offsets, Tensor indices_counts, int o_scale) -> Tensor");
     m.def("residual_ln_modulate(Tensor x, Tensor? y, Tensor? gate, Tensor shift, Tensor scale, float eps) -> Tensor[]");
     m.def("transpose_last2(Tensor x) -> Tensor");
+    m.def("block_mean(Tensor x, int mbm) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
     m.def("gather_rows(Tensor src, Tensor map) -> Tensor");
@@ -778,6 +791,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("mask_to_sorted_indices", &mask_to_sorted_indices);
     m.impl("topk_mask", &topk_mask);
     m.impl("transpose_last2", &transpose_last2);
+    m.impl("block_mean", &block_mean);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);
     m.impl("gather_rows", &gather_rows);

@@ -17,8 +17,12 @@ from ..util.storage import MlpStorage
 
 
 def block_mean(x: torch.Tensor, mbm: int) -> torch.Tensor:
-    """[b, n, c] -> [b, n/mbm, c] mean over consecutive row blocks."""
+    """[b, n, c] -> [b, n/mbm, c] mean over consecutive row blocks (reference modules/mlp.py:11-16).  bf16 GPU tensors take the
+    one-pass kernel (``mlp.fused_block_mean``: fp32 sums, one rounding -- torch's reduction in another summation order)."""
     b, n, c = x.shape
+    if (x.is_cuda and x.dtype == torch.bfloat16 and mbm % 4 == 0 and c % 8 == 0 and n % mbm == 0
+            and amd_key("mlp", "fused_block_mean")):
+        return torch.ops.chipmunk.block_mean(x, mbm)
     return x.reshape(b, n // mbm, mbm, c).mean(dim=2)
 
 

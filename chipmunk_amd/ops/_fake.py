@@ -67,6 +67,10 @@ def _register():
     def _(cs, k, random_amount, groups, static_mask):
         return cs.new_empty(cs.shape, dtype=torch.bool)
 
+    @lib.register_fake("chipmunk::block_mean")
+    def _(x, mbm):
+        return x.new_empty((x.shape[0], x.shape[1] // mbm, x.shape[2]))
+
     @lib.register_fake("chipmunk::bitpack")
     def _(mask):
         return mask.new_empty(((mask.numel() + 7) // 8,), dtype=torch.uint8)

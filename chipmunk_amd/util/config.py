@@ -83,6 +83,8 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "attn.sorted_indices": True,
     # one kernel for |block-mean delta| -> topk_indices -> copy_indices in the sparse MLP step (bm == mbm only)
     "mlp.fused_topk_delta": True,
+    # block means of the MLP input (first op of every sparse MLP step) as one HBM-rate kernel instead of torch's reshape + mean
+    "mlp.fused_block_mean": True,
     # sparse attention step as ONE kernel (cache + delta -> new tensor) instead of clone + in-place accumulate
     "attn.fused_residual": True,
     # mask-building step: randint + topk + scatter_ + mask combines of `random_and_topk` as one kernel

@@ -244,6 +244,11 @@ int chipmunk_copy_indices(const void *src, void *dst, const int32_t *inds, const
  * of the sparse MLP's full step (reference src/chipmunk/modules/mlp.py:56) at HBM rate. */
 int chipmunk_transpose16(const void *src, void *dst, int B, int R, int C, void *stream);
 
+/* [rows, C] bf16 -> [rows / mbm, C] bf16: mean over consecutive blocks of `mbm` rows, fp32 sums, one rounding (the caller's
+ * `block_mean(x, mbm)` in front of the fc1 probe of every sparse MLP step, src/chipmunk/modules/mlp.py:11-16,62).  rows % mbm == 0,
+ * mbm % 4 == 0, C % 8 == 0. */
+int chipmunk_block_mean(const void *x, void *out, int64_t rows, int C, int mbm, void *stream);
+
 /* bitpack / bitunpack (reference src/chipmunk/ops/bitpack.py:4-69): 8 bools -> 1 byte, little-endian, flat. */
 int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream);
 int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);

@@ -246,3 +246,19 @@ def test_c_abi_called_directly_without_the_torch_registry(dev):
     rc = lib.chipmunk_mask_to_indices(None, ctypes.c_void_p(inds.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
                                       ctypes.c_int64(rows), ctypes.c_int(n), ctypes.c_int(pad_n), ctypes.c_int(128), stream)
     assert rc != 0 and _native.last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,mbm", [((1, 4352, 3072), 128), ((2, 256, 1000), 128), ((1, 384, 8), 64), ((1, 3840, 1536), 128)])
+def test_block_mean_kernel_vs_torch(dev, shape, mbm):
+    """chipmunk.block_mean == x.reshape(b, n/mbm, mbm, c).mean(2) (reference modules/mlp.py:11-16): both are fp32 sums rounded once,
+    in different summation orders -- equal within one bf16 unit in the last place, and exactly equal on integer-valued rows."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, generator=g).to(torch.bfloat16).to(dev)
+    got = torch.ops.chipmunk.block_mean(x, mbm)
+    want = x.reshape(shape[0], shape[1] // mbm, mbm, shape[2]).float().mean(dim=2)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    err = (got.float() - want).abs()
+    assert (err <= want.abs() * 2.0 ** -8 + 1e-6).all(), float(err.max())
+    xi = torch.randint(-8, 9, shape, generator=g).to(torch.bfloat16).to(dev)     # exact in fp32 in any order
+    assert torch.equal(torch.ops.chipmunk.block_mean(xi, mbm), xi.reshape(shape[0], shape[1] // mbm, mbm, shape[2]).mean(dim=2))

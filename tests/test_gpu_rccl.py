@@ -94,3 +94,29 @@ def test_sharded_pipelines_two_ranks_on_one_gpu():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret, True), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_bench_two_ranks_over_rccl_reports_transport_and_exposed_communication():
+    """`bench.py --gpus 2` on the real transport (>= 2 GPUs): the launcher, RCCL initialisation with its recorded settings, the
+    chunk planner fed by a measured exchange, and the exposed-communication probe of the sparse steps -- asserted, not just run
+    (on the one-GPU boxes the same line is rehearsed over gloo by tests/test_gpu_bench_contract.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs on the node (RCCL over xGMI)")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    first = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-only"], capture_output=True, text=True, timeout=600)
+    assert first.returncode == 0, first.stderr[-2000:]
+    lo = json.loads(first.stdout.strip().splitlines()[-1])
+    assert lo["backend"].startswith("nccl") and lo["rank_sum"] == 1 and lo["rccl"]["init"].startswith("nccl")
+    assert lo["collectives"]["all_to_all_single"]["payload_ok"] and lo["collectives"]["all_gather_into_tensor"]["payload_ok"]
+    for mode in ("heads", "groups"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sp-mode", mode, "--grid", "8,12,16", "--layers", "3",
+                            "--steps", "3", "--warmup", "3"], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 2 and d["config"]["dist_world_size"] == 2 and d["config"]["sp_mode"] == mode
+        assert d["config"]["rccl"]["init"].startswith("nccl") and d["config"]["rccl"]["rccl_version"]
+        assert "rehearsal" not in d["config"] and d["value"] > 0
+        assert 0.0 <= d["exposed_comm"]["exposed_fraction"] <= 1.0
