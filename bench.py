@@ -1356,6 +1356,11 @@ def main():
     if wan:
         line.update(wan_extra["line"]())
     line.update(extra)
+    try:    # 0 in a healthy run: every refused request for the multi-GB column-sum scratch sent a mask step down a slower route
+        from chipmunk_amd import _native
+        line["big_scratch_fallbacks"] = int(_native.lib().chipmunk_big_scratch_fallbacks())
+    except Exception:       # noqa: BLE001
+        pass
     if dense_sps is not None and "schedule_projection_50_steps" in extra:
         def ratios(node):
             node["sparse_over_dense"] = node["steps_per_s"] / dense_sps

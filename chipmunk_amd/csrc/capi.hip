@@ -93,11 +93,13 @@ void *chipmunk_scratch(hipStream_t stream, size_t bytes) {
 // dense_colsum_attn pass: 10.6 GB of bf16 at HunyuanVideo size).  Not zeroed; nullptr if the device cannot spare it (the
 // caller then takes smaller head chunks or the two-pass route).  The buffer lives outside torch's caching allocator, so it is
 // bounded: never more than option `big_scratch_gb` GiB (default 24) and never more than the free memory minus a 4 GiB
-// reserve at the time of the request; a size that failed is remembered, so failing hipMallocs are not retried on every call;
+// reserve at the time of the request; a size that failed is remembered for a while, so failing hipMallocs are not retried on every call;
 // chipmunk_release_scratch() gives everything back.
 namespace {
 std::map<std::pair<int, hipStream_t>, Scratch> g_big;
-std::map<int, size_t> g_big_failed;   // per device: smallest request that could not be served
+struct BigFail { size_t want, free_then; int calls_left; };
+std::map<int, BigFail> g_big_failed;   // per device: smallest request that could not be served, and when to try again
+int g_big_fallbacks = 0;               // requests answered with nullptr since the last release (bench.py reports it)
 }
 void *chipmunk_big_scratch(hipStream_t stream, size_t bytes) {
     int dev = 0;
@@ -108,24 +110,43 @@ void *chipmunk_big_scratch(hipStream_t stream, size_t bytes) {
     const int cap_gb = chipmunk_get_option("big_scratch_gb");
     const size_t cap = (size_t)(cap_gb > 0 ? cap_gb : 24) << 30;
     const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-    if (want > cap) return nullptr;
-    auto f = g_big_failed.find(dev);
-    if (f != g_big_failed.end() && want >= f->second) return nullptr;
+    if (want > cap) return ++g_big_fallbacks, nullptr;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b + s.bytes - std::min(free_b + s.bytes, (size_t)4 << 30)) {
-        g_big_failed[dev] = f == g_big_failed.end() ? want : std::min(f->second, want);
+    const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    auto f = g_big_failed.find(dev);
+    if (f != g_big_failed.end() && want >= f->second.want) {
+        // a remembered failure is not for ever: hipMemGetInfo does not see torch's cached blocks, so one transient low
+        // moment must not switch the one-pass column-sum route off for good -- try again once noticeably more memory is free than
+        // at the time of the failure, or every 64th request
+        const bool more_free = have_info && free_b > f->second.free_then + ((size_t)1 << 30);
+        if (!more_free && --f->second.calls_left > 0) return ++g_big_fallbacks, nullptr;
+        g_big_failed.erase(f);
+        f = g_big_failed.end();
+    }
+    auto failed = [&]() {
+        g_big_failed[dev] = BigFail{f == g_big_failed.end() ? want : std::min(f->second.want, want), free_b, 64};
+        ++g_big_fallbacks;
         return nullptr;
+    };
+    // the old buffer is given back BEFORE the larger one is requested (the headroom test below counts its bytes as free, so the
+    // request has to be able to use them); contents are scratch, nothing is lost
+    if (have_info && want > free_b + s.bytes - std::min(free_b + s.bytes, (size_t)4 << 30)) return failed();
+    if (s.ptr) {
+        (void)hipStreamSynchronize(stream);   // earlier launches on this stream may still be using the old buffer
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr, s.bytes = 0;
     }
     void *ptr = nullptr;
-    if (s.ptr) (void)hipStreamSynchronize(stream);   // earlier launches on this stream may still be using the old buffer
     if (hipMalloc(&ptr, want) != hipSuccess) {
         (void)hipGetLastError();
-        g_big_failed[dev] = f == g_big_failed.end() ? want : std::min(f->second, want);
-        return nullptr;                               // (the smaller buffer, if any, stays)
+        return failed();
     }
-    if (s.ptr) (void)hipFree(s.ptr);
     s.ptr = ptr, s.bytes = want;
     return ptr;
+}
+extern "C" int chipmunk_big_scratch_fallbacks(void) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    return g_big_fallbacks;
 }
 extern "C" int chipmunk_release_scratch(void) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -134,6 +155,7 @@ extern "C" int chipmunk_release_scratch(void) {
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     g_big.clear();
     g_big_failed.clear();
+    g_big_fallbacks = 0;
     for (auto &kv : g_scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     g_scratch.clear();

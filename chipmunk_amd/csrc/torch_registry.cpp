@@ -175,7 +175,10 @@ std::vector<at::Tensor> residual_ln_modulate(at::Tensor x, const c10::optional<a
     check(chipmunk_residual_ln_modulate(x.data_ptr(), res ? yc.data_ptr() : nullptr, res ? gc.data_ptr() : nullptr, sh.data_ptr(),
                                         sc.data_ptr(), res ? xo.data_ptr() : nullptr, xm.data_ptr(), rows, (int)C, eps, cur_stream(x)),
           "residual_ln_modulate");
-    return {res ? xo : x, xm};
+    // without a residual the input is not handed back: an operator's outputs must not alias its inputs (the schema declares fresh
+    // tensors; functionalisation / torch.compile rely on it) -- the Python wrapper returns the caller's x beside xm
+    if (res) return {xo, xm};
+    return {xm};
 }
 
 // reference csrc/attn/csp_128_attn.cu:355-461

@@ -84,7 +84,10 @@ class SparseDiffAttn(nn.Module):
         """(static mask, sparse-group flags) for this module's heads and query groups.  The shared tensors hold
         ``local_heads_num`` identical head planes (reference attn.py:67); a module serving fewer heads takes a prefix."""
         g0 = self.query_group_offset
-        h = min(heads, singleton_static_mask.shape[1])
+        assert heads <= singleton_static_mask.shape[1] or singleton_static_mask.shape[1] == 1, (
+            f"this module serves {heads} heads but initialize_static_mask() built {singleton_static_mask.shape[1]} head planes "
+            "(local_heads_num): build the static mask for the largest head chunk")
+        h = min(heads, singleton_static_mask.shape[1])      # (one plane broadcasts over the heads)
         return (singleton_static_mask[:, :h, g0:g0 + qg, :n], singleton_video_query_groups[:, :h, g0:g0 + qg, :])
 
     def random_and_topk(self, cs: Tensor, topk: int) -> Tensor:
@@ -104,6 +107,21 @@ class SparseDiffAttn(nn.Module):
         return mask
 
     # ------------------------------------------------------------------------------------------ helpers
+    def release_kept_indices(self) -> None:
+        """Give the HBM booked for the kept index rows back to the residency budget (a module that is dropped or rebuilt -- new model,
+        new resolution -- would otherwise leave its share booked for the life of the process)."""
+        for inv, old in enumerate(self._unpacked):
+            if old is not None:
+                release_resident(old[3])
+                self._unpacked[inv] = None
+
+    def __del__(self):
+        try:
+            self.release_kept_indices()
+        except Exception:       # noqa: BLE001  (interpreter shutdown: the budget module may be gone)
+            pass
+
+    @torch.compiler.disable
     def _remember_indices(self, inds: Tensor, counts: Tensor) -> None:
         """``attn.keep_unpacked_indices``: keep what the bit-packed mask just stored unpacks to, while that mask itself stays in
         HBM -- as ragged rows (``ops.compact_indices``: the kept keys back to back; the padded ``[B, H, G, N]`` int32 tensor is 7 GB per

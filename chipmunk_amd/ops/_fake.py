@@ -23,7 +23,7 @@ def _register():
 
     @lib.register_fake("chipmunk::residual_ln_modulate")
     def _(x, y, gate, shift, scale, eps):
-        return [torch.empty_like(x) if y is not None else x, torch.empty_like(x)]
+        return [torch.empty_like(x), torch.empty_like(x)] if y is not None else [torch.empty_like(x)]
 
     @lib.register_fake("chipmunk::csp_attn_out_ragged")
     def _(q, k, v, o_in, indices, offsets, indices_counts, o_scale):
@@ -48,7 +48,7 @@ def _register():
     def _(q, k, v, p):
         groups = (q.shape[2] + 191) // 192
         return [_o_like(q, False),
-                q.new_empty((q.shape[0], q.shape[1], groups, q.shape[2])),
+                q.new_empty((q.shape[0], q.shape[1], groups, max(q.shape[2], k.shape[2]))),
                 q.new_empty((q.shape[0], q.shape[1], q.shape[2], 1), dtype=torch.float32)]
 
     @lib.register_fake("chipmunk::mask_to_indices")

@@ -54,7 +54,8 @@ def residual_ln_modulate(x: torch.Tensor, y: Optional[torch.Tensor], gate: Optio
     ``x = x + gate * y`` first (``models.py:262-275, 431``), then ``xm = LayerNorm(x) * (1 + scale) + shift`` (``modulate(norm(x))``,
     ``models.py:184-186``; LayerNorm without affine).  Returns ``(x, xm)``.  On CPU tensors: the reference's torch sequence."""
     if x.is_cuda:
-        return tuple(torch.ops.chipmunk.residual_ln_modulate(x, y, gate, shift, scale, eps))
+        out = torch.ops.chipmunk.residual_ln_modulate(x, y, gate, shift, scale, eps)
+        return (out[0], out[1]) if y is not None else (x, out[0])      # (the operator never returns its own input)
     if y is not None:
         x = torch.addcmul(x, gate, y)
     xn = torch.nn.functional.layer_norm(x, (x.shape[-1],), eps=eps)

@@ -264,6 +264,9 @@ int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t
 /* Gives back the library's device scratch (work plans, split partials, the multi-GB partial column sums of the fused
  * dense_colsum_attn pass -- bounded by option "big_scratch_gb", default 24).  Synchronises the device. */
 int chipmunk_release_scratch(void);
+/* How many requests for the multi-GB column-sum scratch were refused since the last release (each one sent a dense_colsum_attn /
+ * dense_colsum_topk_mask call down the slower two-pass or chunked route): 0 in a healthy run. */
+int chipmunk_big_scratch_fallbacks(void);
 
 /* ---------------------------------------------------------------- projection output -> attention operands
  * qkv [n rows of row_stride elements, the first 3*heads*128 of each = (q|k|v, head, 128)] bf16  ->  q, k, v [heads, n, 128] bf16
