@@ -780,6 +780,42 @@ class Hunyuan:
         return {"q_scale": scale, "sparse_step_s": sum(t for _, _, t in times) / len(times),
                 "csp_128_attn_avg_ms": None if summ is None else round(summ["avg_ms"], 4)}
 
+    def qk_norm_gain_leg(self, timer, sigma=0.5, sparse_steps=2):
+        """q and k as a trained model's qk-norm would leave them: RMSNorm over the head dimension times a per-channel gain,
+        log-normal with sigma 0.5 (N(0,1) inputs have every |q| ~ sqrt(128); learned gains spread the norms).  Reports how many waves of
+        the gathered kernel can still prove its bound |q_i| max_j|k_j| c <= 55 (the loop without a reference point) --
+        evaluated with the kernel's own formula on the tensors -- and what the sparse step and the kernel launch cost then.  The masks
+        are those of the main run (same key counts, same work)."""
+        g = torch.Generator(device=self.dev).manual_seed(4321)
+        gq = torch.exp(sigma * torch.randn(self.D, generator=g, device=self.dev))
+        gk = torch.exp(sigma * torch.randn(self.D, generator=g, device=self.dev))
+        saved = self.qkv
+        def norm(t, gain):
+            tf = t.float()
+            return (tf * torch.rsqrt(tf.pow(2).mean(-1, keepdim=True) + 1e-6) * gain).to(torch.bfloat16)
+        self.qkv = [[norm(q, gq), norm(k, gk), v] for q, k, v in saved]
+        fast = []
+        for q, k, _ in self.qkv:
+            qn = q.float().norm(dim=-1)                              # [1, H, N]
+            kmax = k.float().norm(dim=-1).amax(dim=-1, keepdim=True)  # [1, H, 1]
+            bound = qn * kmax * (0.08838834764 * 1.44269504089)
+            pad = (-bound.shape[-1]) % 96
+            b96 = torch.nn.functional.pad(bound, (0, pad)).view(bound.shape[0], bound.shape[1], -1, 96).amax(-1)   # one wave = 96 query rows
+            fast.append(float((b96 <= 55.0).float().mean().item()))
+            del qn, kmax, bound, b96
+        before = {k_: list(v_) for k_, v_ in timer.records.items()}
+        timer.records = {}
+        timer.enabled = True
+        times = self.run_steps(12, sparse_steps)
+        timer.enabled = False
+        summ = timer.summary().get("csp_128_attn")
+        timer.records = before
+        self.qkv = saved
+        return {"gain_sigma": sigma, "waves_on_the_loop_without_reference_point": sum(fast) / len(fast),
+                "sparse_step_s": sum(t for _, _, t in times) / len(times),
+                "csp_128_attn_avg_ms": None if summ is None else round(summ["avg_ms"], 4),
+                "what": "q, k = RMSNorm(N(0,1)) x log-normal per-channel gains: the data-dependent loop choice of the gathered kernel on norm-spread inputs"}
+
     def no_fused_rowwise_leg(self, sparse_step_s, computed_steps, elapsed, steps, sparse_steps=2):
         """What UNCHANGED model code would see: the block's gated residual + LayerNorm + modulate as the reference's torch ops
         instead of chipmunk.residual_ln_modulate (an operator outside the reference's surface).  Two sparse
@@ -1285,6 +1321,7 @@ def main():
                     computed = sum(1 for _, kind, _ in timed_times if kind != "skipped")
                     extra["no_fused_rowwise_leg"] = wl.no_fused_rowwise_leg(mean["sparse"], computed, elapsed, args.steps)
                 extra["running_max_fallback_leg"] = wl.qk_scale_leg(args.qk_scale, timer)
+                extra["qk_norm_gain_leg"] = wl.qk_norm_gain_leg(timer)
                 if not args.no_projections:
                     extra["round2_step_definition_leg"] = wl.round2_definition_leg(mean, extra["timed_steps"]["kinds"])
             if not args.no_82 and args.top_keys is None:

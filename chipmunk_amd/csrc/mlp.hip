@@ -105,39 +105,49 @@ struct TileMap {
     int g, nt, sub;  // sub < 0: whole tile
     bool live;
 };
+// The part of the map that is the same for every tile of a workgroup: live column tiles, this XCD's share and where its tail begins.
+struct TilePlan {
+    int G, NR, NTl, mine, full, base, nsub;
+    // workgroup slots of this XCD that carry work: whole tiles, then the tail's sub-tiles
+    __device__ __forceinline__ int slots() const { return full + (mine - full) * nsub; }
+};
 template <int BN>
-__device__ __forceinline__ TileMap map_tile(const int32_t *counts, int G, int NTmax, int NR, int slots_per_xcd = 0,
-                                            int nsub = 1) {
+__device__ __forceinline__ TilePlan plan_tiles(const int32_t *counts, int G, int NTmax, int NR, int slots_per_xcd = 0, int nsub = 1) {
     int cmax = 0;  // wave-parallel max (a scalar loop over G costs ~50 ns per group, per workgroup)
     for (int g = threadIdx.x & 63; g < G; g += 64) cmax = max(cmax, counts[g]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
     cmax = __builtin_amdgcn_readfirstlane(cmax);
-    const int NTl = min((cmax + BN - 1) / BN, NTmax);
-    const int total = NTl * G;
+    TilePlan pl;
+    pl.G = G, pl.NR = NR, pl.nsub = nsub;
+    pl.NTl = min((cmax + BN - 1) / BN, NTmax);
+    const int total = pl.NTl * G;
     const int xcd = blockIdx.x & 7;
-    int slot = blockIdx.x >> 3;
     const int q = total >> 3, r = total & 7;
-    const int mine = q + (xcd < r ? 1 : 0);  // tiles of this XCD
+    pl.mine = q + (xcd < r ? 1 : 0);  // tiles of this XCD
+    pl.full = pl.mine;
+    if (nsub > 1 && slots_per_xcd > 0) {
+        const int rem = pl.mine % slots_per_xcd;
+        if (pl.mine > slots_per_xcd && rem > 0 && rem * nsub <= slots_per_xcd) pl.full = pl.mine - rem;
+    }
+    pl.base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return pl;
+}
+__device__ __forceinline__ TileMap tile_at(const TilePlan &pl, int slot) {
     TileMap m;
     m.sub = -1;
-    int full = mine;
-    if (nsub > 1 && slots_per_xcd > 0) {
-        const int rem = mine % slots_per_xcd;
-        if (mine > slots_per_xcd && rem > 0 && rem * nsub <= slots_per_xcd) full = mine - rem;
+    if (slot >= pl.full) {
+        const int k = slot - pl.full;
+        m.sub = k % pl.nsub;
+        slot = pl.full + k / pl.nsub;
     }
-    if (slot >= full) {
-        const int k = slot - full;
-        m.sub = k % nsub;
-        slot = full + k / nsub;
-    }
-    m.live = slot < mine;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int per = G * NR;
+    m.live = slot < pl.mine;
+    const int t = pl.base + slot;
+    const int per = pl.G * pl.NR;
     const int nb = t / per, rem = t - nb * per;
-    const int nr = min(NR, NTl - nb * NR);
+    const int nr = min(pl.NR, pl.NTl - nb * pl.NR);
     m.g = nr > 0 ? rem / nr : 0;
-    m.nt = nb * NR + (nr > 0 ? rem - m.g * nr : 0);
+    m.nt = nb * pl.NR + (nr > 0 ? rem - m.g * nr : 0);
     return m;
 }
 
@@ -437,19 +447,29 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MPROF_ABS(0);
     constexpr int NSUB = 2 * (BN / 64);  // 64 x 64 sub-tiles per tile
-    const TileMap tm = map_tile<BN>(p.counts, p.M / BM, p.NT, p.NR, p.slots_per_xcd, NSUB);
-    if (!tm.live) return;
-    const int g = tm.g;
-    const int cnt = p.counts[g];
-    if (tm.sub < 0) {
-        const int n0 = tm.nt * BN;
-        if (n0 >= cnt) return;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
-        mm1_tile<BM, BN, BK, NST, FP8>(p, smem, g, 0, n0, cnt);
-    } else {
-        constexpr int SUB_NST = (NST * (BM + BN)) / 128;  // same LDS bytes, stages of 64 + 64 rows
-        const int n0 = tm.nt * BN + (tm.sub >> 1) * 64;
-        if (n0 >= cnt || p.probe == 3) return;  // probe 3: time the launch without its tail
-        mm1_tile<64, 64, BK, (SUB_NST > 4 ? 4 : SUB_NST), FP8>(p, smem, g, (tm.sub & 1) * 64, n0, cnt);
+    // PERSISTENT workgroups: the grid is the resident slots (WPS per CU); a workgroup walks its XCD's tile list with the stride of the
+    // XCD's slots -- the same tile-to-slot order a one-tile-per-workgroup grid is dispatched in, without the relaunch between tiles
+    // (kernel arguments, the live-tile map, wave start-up: 5.4 k of a 41 k-cycle tile at the Wan2.1 fp8 shape, tools/mlp_prof.py) and
+    // with the previous tile's stores draining under the next tile's index loads.  (Requesting the NEXT tile's gather indices during
+    // the current tile -- one exposed round trip less -- measured no gain at the fp8 shape, 209 vs 209-224 us, for 40 more registers.)
+    const TilePlan pl = plan_tiles<BN>(p.counts, p.M / BM, p.NT, p.NR, p.slots_per_xcd, NSUB);
+    const int nslots = pl.slots(), stride = (int)(gridDim.x >> 3);
+    for (int slot = blockIdx.x >> 3; slot < nslots; slot += stride) {
+        const TileMap tm = tile_at(pl, slot);
+        if (!tm.live) continue;
+        const int g = tm.g;
+        const int cnt = p.counts[g];
+        if (tm.sub < 0) {
+            const int n0 = tm.nt * BN;
+            if (n0 >= cnt) continue;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
+            mm1_tile<BM, BN, BK, NST, FP8>(p, smem, g, 0, n0, cnt);
+        } else {
+            constexpr int SUB_NST = (NST * (BM + BN)) / 128;  // same LDS bytes, stages of 64 + 64 rows
+            const int n0 = tm.nt * BN + (tm.sub >> 1) * 64;
+            if (n0 >= cnt || p.probe == 3) continue;  // probe 3: time the launch without its tail
+            mm1_tile<64, 64, BK, (SUB_NST > 4 ? 4 : SUB_NST), FP8>(p, smem, g, (tm.sub & 1) * 64, n0, cnt);
+        }
+        __syncthreads();   // the next tile's DMA lands where this tile's epilogue was reading
     }
 }
 
@@ -558,7 +578,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
         MPROF_MARK(0);
         __builtin_amdgcn_s_barrier();
         MPROF_MARK(1);
-        if (kb + NST - 1 < nkb) {
+        // An 8-wave workgroup puts waves w and w + 4 on the same SIMD, locked to each other by the barrier: both would issue their DMA
+        // pieces first and want the matrix pipe afterwards.  The second wave of each SIMD issues its pieces AFTER its MFMAs instead, so
+        // the pair is in complementary phases (same-box A/B, FLUX shape: 154.8 -> 148.7 us; p.probe & 8 switches it off).
+        const bool late = NW == 8 && !(p.probe & 8) && w >= NW / 2;
+        if (!late && kb + NST - 1 < nkb) {
             issue(kb + NST - 1, nbuf);
             if (kb + NST < nkb) load_keys(kb + NST);  // (moving these behind the MFMAs measured 15 % slower)
         }
@@ -598,6 +622,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
                 for (int mt = 0; mt < 2; ++mt)
                     acc[n4][mt] = mfma32(wf[kk & 1][n4], pf[kk & 1][mt], acc[n4][mt]);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (late && kb + NST - 1 < nkb) {
+            issue(kb + NST - 1, nbuf);
+            if (kb + NST < nkb) load_keys(kb + NST);
         }
         MPROF_MARK(3);
         buf = buf + 1 == NST ? 0 : buf + 1;
@@ -799,11 +827,12 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated =
     p.NT = (p.F + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
-    // tail split: WPS workgroups per CU are resident; the grid carries room for the sub-tile workgroups of each XCD
-    constexpr int NSUB = 2 * (BN / 64);
-    p.slots_per_xcd = chipmunk_get_option("mm1_no_split") ? 0 : WPS * device_cu_count() / 8;
-    const int per_xcd = ((p.M / BM) * p.NT + 7) / 8 + (p.slots_per_xcd > 0 ? p.slots_per_xcd : 0);
-    (void)NSUB;
+    // tail split: WPS workgroups per CU are resident; an XCD's leftover tiles are handed out as sub-tiles at the end of its list
+    const int resident_per_xcd = WPS * device_cu_count() / 8;
+    p.slots_per_xcd = chipmunk_get_option("mm1_no_split") ? 0 : resident_per_xcd;
+    // persistent grid: the resident slots, or fewer when the launch has fewer tiles than slots (every tile gets its own workgroup)
+    const int tiles_per_xcd = ((p.M / BM) * p.NT + 7) / 8;
+    const int per_xcd = tiles_per_xcd < resident_per_xcd ? tiles_per_xcd : resident_per_xcd;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
