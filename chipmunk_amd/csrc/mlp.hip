@@ -12,6 +12,7 @@
 // ds_read_b64_tr_b16 (fc2^T, which is n-contiguous in memory and must be fed k-contiguous to the MFMA).  Epilogues go
 // through the freed ring so that global memory only sees 16-byte accesses over whole row segments.
 #include "common.h"
+#include "attn64_util.h"
 #include <type_traits>
 
 namespace {
@@ -532,7 +533,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
         // counts are multiples of 8 and so is the block start: the block is live or dead as a whole, which lets the
         // compiler fetch it with ONE wide scalar load instead of NKEY single ones
         const int base = kb * BK + w * NKEY;
-        const int32_t *kp = idxg + __builtin_amdgcn_readfirstlane(base < cnt ? base : 0);
+        // through the CONSTANT address space: the compiler then emits s_load (lgkmcnt).  As a plain global pointer it loaded the keys with
+        // a vector global_load -- on the vmcnt counter, so the use of a key one k step later drained every LDS-DMA in flight
+        // (s_waitcnt vmcnt(0) in the middle of the ring: the prefetch depth of the ring was never there)
+        const __attribute__((address_space(4))) int32_t *kp =
+            (const __attribute__((address_space(4))) int32_t *)(idxg + __builtin_amdgcn_readfirstlane(base < cnt ? base : 0));
 #pragma unroll
         for (int j = 0; j < NKEY; ++j) keys[j] = kp[j];
     };
@@ -587,42 +592,62 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
             if (kb + NST < nkb) load_keys(kb + NST);  // (moving these behind the MFMAs measured 15 % slower)
         }
         MPROF_MARK(2);
-        const unsigned char *At = smem + buf * STAGE;
-        const unsigned char *Bt = At + A_TILE;
+        // Operand fragments by inline-asm LDS reads with hand-counted lgkmcnt: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
+        // it knows about while an LDS-DMA is in flight (it cannot tell the ring slots apart), which drained the two stages the ring is
+        // meant to keep flying.  Reads return in order; a scalar key load in flight only makes a counted wait conservative.
         constexpr int KK = BK / 16;
-        bf16x8 pf[2][2], wf[2][NT4];
-        auto load_frags = [&](int kk, int set) {
-            const bool kdead = kb * BK + kk * 16 + (lane >> 5) * 8 >= cnt;  // counts are multiples of 8
+        constexpr int RD = 2 + 2 * NT4;   // LDS reads per k slice: two A fragments, two halves per B fragment
+        const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + buf * STAGE;
+        u32x4 pf[KK][2];
+        u32x2 wlo[KK][NT4], whi[KK][NT4];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                bf16x8 z = {};
-                const bf16x8 v = KT::frag(At, wm * 64 + mt * 32 + (lane & 31), kk, lane);
-                pf[set][mt] = kdead ? z : v;  // packed columns past the count hold garbage
+                const int row = wm * 64 + mt * 32 + (lane & 31);
+                const uint32_t ad = stage_lds + row * KT::ROWB + (((kk * 2 + (lane >> 5)) ^ KT::swz(row)) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=&v"(pf[kk][mt]) : "v"(ad) : "memory");
             }
 #pragma unroll
             for (int n4 = 0; n4 < NT4; ++n4) {
                 // lane group grp: n half = grp&1, k half = grp>>1; lane li addresses block row li>>2, cols (li&3)*4
                 const int row = kk * 16 + (grp >> 1) * 8 + (li >> 2);
                 const int chunk = (wn * (BN / WNG / 8) + n4 * 4 + (grp & 1) * 2 + ((li & 3) >> 1)) ^ ((row & 3) << 2);
-                const unsigned char *ba = Bt + row * BROWB + chunk * 16 + (li & 1) * 8;
-                const s16x4 lo = lds_read_tr16_b64(ba);
-                const s16x4 hi = lds_read_tr16_b64(ba + 4 * BROWB);
-                wf[set][n4] = __builtin_bit_cast(
-                    bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                const uint32_t ad = stage_lds + A_TILE + row * BROWB + chunk * 16 + (li & 1) * 8;
+                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%c3"
+                             : "=&v"(wlo[kk][n4]), "=&v"(whi[kk][n4]) : "v"(ad), "i"(4 * BROWB) : "memory");   // (early clobber: a result
+                // register shared with the address would be overwritten by the first read's return if the second one queues behind it)
             }
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n4 = 0; n4 < NT4; ++n4)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[n4][mt] = mfma32(wf[kk & 1][n4], pf[kk & 1][mt], acc[n4][mt]);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        if (kb == nkb - 1) {   // packed columns past the count hold garbage: only the last k step can see them (counts are multiples of 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const bool kdead = kb * BK + kk * 16 + (lane >> 5) * 8 >= cnt;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    asm volatile("" : "+v"(pf[kk][mt]));
+                    if (kdead) pf[kk][mt] = (u32x4){0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        static_for<0, KK>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            // slice kk has landed once at most the reads of the younger slices are outstanding; the operands pin the MFMAs below the wait
+            constexpr int YOUNGER = RD * (KK - 1 - kk);   // (the counter has 4 bits: a smaller number only waits for more)
+            asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(YOUNGER > 15 ? 15 : YOUNGER) : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(pf[kk][i]));
+#pragma unroll
+            for (int i = 0; i < NT4; ++i) asm volatile("" : "+v"(wlo[kk][i]), "+v"(whi[kk][i]));
+#pragma unroll
+            for (int n4 = 0; n4 < NT4; ++n4) {
+                const bf16x8 wfr = __builtin_bit_cast(bf16x8, (u32x4){wlo[kk][n4][0], wlo[kk][n4][1], whi[kk][n4][0], whi[kk][n4][1]});
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[n4][mt] = mfma32(wfr, __builtin_bit_cast(bf16x8, pf[kk][mt]), acc[n4][mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (late && kb + NST - 1 < nkb) {
             issue(kb + NST - 1, nbuf);
             if (kb + NST < nkb) load_keys(kb + NST);

@@ -44,11 +44,22 @@ def test_hunyuan_line_with_its_legs():
     assert set(d["kernels"]) >= {"dense_attn", "csp_128_attn"}
     comp = d["dense_gpu_comparator"]
     assert comp["sparse_over_dense"] > 1.0 and "FLASH" in comp["backend"] and comp["own_dense"]["sparse_over_own_dense"] > 1.0
-    leg = d["step_caching_leg"]
-    assert leg["skipped"] == 6 and leg["kinds"].count("sparse") == 3 and leg["steps_per_s"] > d["value"]
+    # the default run executes the shipped skip schedule in its timed region (BASELINE configs[2] "+ step caching") and reports what
+    # unchanged model code (no fused row-wise operator) and norm-spread q / k would see
+    assert d["config"]["step_caching"] is True and "step_caching_leg" not in d
+    assert d["no_fused_rowwise_leg"]["sparse_step_s"] > 0 and d["no_fused_rowwise_leg"]["timed_region_steps_per_s_equivalent"] > 0
+    assert 0.0 <= d["qk_norm_gain_leg"]["waves_on_the_loop_without_reference_point"] <= 1.0 and d["qk_norm_gain_leg"]["csp_128_attn_avg_ms"] > 0
+    assert "aotriton" in d["sdpa_flash_libraries"] and "ck" in d["sdpa_flash_libraries"] and d["big_scratch_fallbacks"] == 0
     assert d["running_max_fallback_leg"]["csp_128_attn_avg_ms"] > 0
     assert 0.75 < d["sparsity_82_leg"]["column_sparsity"] < 0.86 and 0.90 < d["column_sparsity"] < 0.95
     assert d["roofline"]["traffic_source"] is None or d["roofline"]["traffic_source"].startswith("profiles/")
+
+
+def test_hunyuan_line_without_the_step_cache_has_the_step_caching_leg():
+    d = _bench("--layers", "4", "--steps", "3", "--warmup", "3", "--no-step-caching", "--no-82", "--dense-steps", "0", "--no-cpu-baseline")
+    assert d["config"]["step_caching"] is False
+    leg = d["step_caching_leg"]
+    assert leg["skipped"] == 6 and leg["kinds"].count("sparse") == 3 and leg["steps_per_s"] > d["value"]
 
 
 @pytest.mark.parametrize("mode,chunks", [("heads", "8,16"), ("groups", "6,18")])
