@@ -536,17 +536,51 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     if (nsp == 1) {
-        // the three blocks' accumulation bases are requested together, before the first accumulator is read: one memory round trip
-        // per item instead of one per block (a lone wave waits them out with nothing else to run)
-        u32x2 base[3][16] = {};
+        // The wave's 96 x 128 bf16 results leave through its own 24 KiB of the (idle) K/V rings: a lane holds 16 x 8 bytes of ONE row per
+        // query block -- stored as they stand that is 48 eight-byte stores per lane (and as many base loads for the accumulate forms), 32
+        // rows x 16 bytes per instruction.  Through LDS (8-byte writes, chunk index XOR row: the 16 lanes of a write group hit 16
+        // different chunks) they become 24 whole-row 16-byte accesses per lane, 4 rows = 1 KiB per instruction; the accumulation base is
+        // requested in that layout before the first accumulator is read (one round trip, under the LDS pass).
+        constexpr int EP_I = 96 * 256 / 1024;   // 24
+        const int er = lane >> 4, ech = lane & 15;
+        const int64_t obase = b * p.os[0] + h * p.os[1];
+        u32x4 base[EP_I] = {};
         if constexpr (INPLACE) {
-            load_base(0, base[0]), load_base(1, base[1]), load_base(2, base[2]);
+#pragma unroll
+            for (int j = 0; j < EP_I; ++j) {
+                const int qrow = row0 + j * 4 + er;
+                if (qrow < p.Nq) base[j] = *(const u32x4 *)(p.o_in + obase + (int64_t)qrow * p.os[2] + ech * 8);
+            }
         }
+        __syncthreads();   // both waves are done with the rings
+        unsigned char *stage = smem + w * (96 * 256);
         static_for<0, 3>([&](auto qq) {
+            constexpr int QB = decltype(qq)::value;
             float o[64];
             read_o(qq, o);
-            store_o(decltype(qq)::value, o, lq[decltype(qq)::value], base[decltype(qq)::value]);
+            const float l = lq[QB];
+            const float inv = (l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f) * (INPLACE ? p.o_scale : 1.f);   // o_scale = +-1: exact
+            const int r = QB * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // bf16(o_scale * result): what the reference stores before its bf16 reduce-add (csp_attn.cu:294-300)
+                const u32x2 out = {pack_bf16x2(o[i * 4 + 0] * inv, o[i * 4 + 1] * inv), pack_bf16x2(o[i * 4 + 2] * inv, o[i * 4 + 3] * inv)};
+                *(u32x2 *)(stage + r * 256 + ((i ^ (r & 15)) << 4) + hf * 8) = out;   // chunk i = d 8i .. 8i+7: this lane's half hf
+            }
         });
+#pragma unroll
+        for (int j = 0; j < EP_I; ++j) {
+            const int r = j * 4 + er, qrow = row0 + r;
+            if (qrow >= p.Nq) continue;
+            u32x4 v = *(const u32x4 *)(stage + r * 256 + ((ech ^ (r & 15)) << 4));
+            if constexpr (INPLACE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack_bf16x2(__uint_as_float(base[j][e] << 16) + __uint_as_float(v[e] << 16),
+                                       __uint_as_float(base[j][e] & 0xffff0000u) + __uint_as_float(v[e] & 0xffff0000u));
+            }
+            *(u32x4 *)(p.o + obase + (int64_t)qrow * p.os[2] + ech * 8) = v;
+        }
 #ifdef ATTN96_PROF
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (prof_on_ && lane == 0) g_a96_prof[w * 8 + 3] = __builtin_amdgcn_s_memtime() - t_loop_end_;   // epilogue incl. the stores landing
