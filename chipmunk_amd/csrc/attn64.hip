@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int DB = decltype(dbc)::value, OFF = decltype(offc)::value;
         u32x2 lo, hi;
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
-                     : "=v"(lo), "=v"(hi) : "v"(vad[DB]), "i"(OFF), "i"(OFF + 2048) : "memory");
+                     : "=&v"(lo), "=&v"(hi) : "v"(vad[DB]), "i"(OFF), "i"(OFF + 2048) : "memory");   // (early clobber: two reads, one address)
         return (u32x4){lo[0], lo[1], hi[0], hi[1]};
     };
 
