@@ -42,8 +42,8 @@ WORKLOADS = {
 
 # rocprofv3 --pmc segfaults on the wan_c5 bench itself (ROCm 7.2; the workload's pinned-host copies on side streams): its two GEMM
 # kernels are profiled on tools/kbench.py's launches at the same shapes instead, and the entry says so
-WORKLOADS["wan_c5_kbench"] = (["@kbench", "fp8_wan", "mm2_wan"],
-                              {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true>"], "mm2_wan": ["mm2_kernel"]},
+WORKLOADS["wan_c5_kbench"] = (["@kbench", "fp8_wan", "mm2_wan", "csp_hunyuan"],   # (the gathered kernel at 12 heads x 32 760 tokens, 8 832 keys per group: the bench's mean)
+                              {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true>"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"]},
                               "tools/kbench.py launches at the wan_c5 shapes (M 32 768, K 1 536, F 8 960, keep 0.3; same buffers every launch), NOT "
                               "the bench's own launches: rocprofv3 --pmc crashes on that workload")
 
@@ -52,6 +52,8 @@ def one_pass(counter, cmd):
     out = os.path.join(ROOT, "gpurun_out", f"pmcb_{counter}")
     subprocess.run(["rm", "-rf", out])
     env = dict(os.environ, TMPDIR="/tmp")
+    if "kbench.py" in cmd[0]:
+        env.update(KB_HEADS="12", KB_N="32760", KB_COUNT_C3="8832")     # only the csp_hunyuan case reads these: the Wan2.1 sequence
     subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable] + cmd,
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
