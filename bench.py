@@ -63,7 +63,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50 hunyuan_c3 = one whole schedule, 20 hunyuan_sp, 50 flux)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5 hunyuan, 50 flux)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 3 hunyuan_c3, 5 hunyuan_sp, 50 flux)")
     ap.add_argument("--workload", default="auto", choices=["auto", "hunyuan_c3", "hunyuan_sp", "flux_c2", "wan_c5"])
     ap.add_argument("--launch-only", action="store_true",
                     help="start the ranks, rendezvous, all-reduce once, print one JSON line with every rank's identity and exit "
@@ -747,7 +747,7 @@ class Hunyuan:
         self.cfg["step_caching"]["is_enabled"] = was
         return out
 
-    def leg_at(self, top_keys, sparse_steps=2):
+    def leg_at(self, top_keys, sparse_steps=1):
         """Re-mask every layer at another sparsity (one mask-recompute step), then time sparse steps."""
         self.cfg["attn"]["top_keys"] = top_keys
         times = self.run_steps(10, 1 + sparse_steps)
@@ -764,7 +764,7 @@ class Hunyuan:
                 "steps_per_s": len(times) / total, "skipped": sum(1 for _, k, _ in times if k == "skipped"),
                 "what": "measured, not projected: skipped steps cost a counter advance and return the stored hidden state"}
 
-    def qk_scale_leg(self, scale, timer, sparse_steps=2):
+    def qk_scale_leg(self, scale, timer, sparse_steps=1):
         """Sparse steps with q multiplied by `scale`: 2 |q| max|k| c exceeds 64, so the gathered kernel cannot prove the fixed
         reference point safe and runs its running-maximum fallback -- the data-dependent slow path made
         driver-visible.  The masks are those of the unscaled run (same key counts, same work)."""
@@ -831,7 +831,7 @@ class Hunyuan:
                 "what": "same schedule with torch's addcmul + layer_norm + modulate kernels in every block (--no-fused-rowwise runs it whole); "
                         "chipmunk.qkv_split_norm stays (its torch form is the caller's rearrange + RMSNorm + rotary code)"}
 
-    def round2_definition_leg(self, mean, kinds_timed, sparse_steps=2):
+    def round2_definition_leg(self, mean, kinds_timed, sparse_steps=1):
         """The same sparse steps under round 2's definition of a step (attention + MLP only): what the projections, norms, rotary
         embedding and residuals added to the block cost, and the timed region's steps/s had they been left out."""
         self.mlp_only = True
@@ -1165,7 +1165,8 @@ def main():
         # window of it (a 20-step window from step 5 holds 11 of the 25 skipped steps and would flatter it)
         args.steps = (50 if args.workload == "hunyuan_c3" and args.step_caching else 20) if hunyuan else 50 if not wan else 10
     if args.warmup is None:
-        args.warmup = 5 if hunyuan else 50 if not wan else 12
+        # hunyuan_c3: steps 0 (dense), 1 (mask), 2 (sparse) run every kernel of the schedule once; any 50-step window is the whole schedule
+        args.warmup = (3 if args.workload == "hunyuan_c3" and args.step_caching else 5) if hunyuan else 50 if not wan else 12
     if args.dense_steps < 0:
         args.dense_steps = 1 if hunyuan else 3 if not wan else 2
 
