@@ -545,9 +545,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
     auto issue = [&](int kb, int buf) {
         unsigned char *st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i) blds16(ra, aoff[i], kb * BK * 2, st + (w * A_INST + i) * 1024);
+        for (int i = 0; i < A_INST; ++i)
+            if (!(p.probe & 32)) blds16(ra, aoff[i], kb * BK * 2, st + (w * A_INST + i) * 1024);   // (timing probe 32: no A pieces)
 #pragma unroll
         for (int i = 0; i < B_INST; ++i) {
+            if (p.probe & 64) continue;                                                        // (timing probe 64: no B pieces)
             int key = keys[i * BRPI];
 #pragma unroll
             for (int rr = 1; rr < BRPI; ++rr) key = rsel == rr ? keys[i * BRPI + rr] : key;
