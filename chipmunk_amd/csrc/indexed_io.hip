@@ -336,14 +336,20 @@ __global__ __launch_bounds__(1024) void topk_indices_kernel(const TopkParams p) 
         }
         const int k = (int)(1024 * p.quantile);
         uint32_t res = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = res | (1u << bit);
+        // |delta| rounded to a 16-bit type: every key is a non-negative float whose LOWZ low bits are zero (bf16: 16, fp16: 13), so
+        // the LOWZ low rounds all ask the same question (#{key <= res} <= k ?) and set all of their bits or none -- one round
+        // decides them, same result bit for bit, 17 rounds instead of 32
+        constexpr int LOWZ = !DELTA ? 0 : std::is_same<T, uint16_t>::value ? 16 : std::is_same<T, _Float16>::value ? 13 : 0;
+        constexpr int LAST = LOWZ ? LOWZ - 1 : 0;
+        for (int bit = 31; bit >= LAST; --bit) {
+            const uint32_t cand = res | (LOWZ && bit == LAST ? (1u << LOWZ) - 1u : (1u << bit));
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) cnt += key[j] < cand ? 1 : 0;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-            if (cnt <= k) res = cand;
+            // wave total by DPP row rotations + two lane swaps (exact in fp32: <= 1024).  Six __shfl_xor steps are six ds_bpermute round
+            // trips per round, 32 rounds in a row on one wave while the other 15 wait: ~10 us of this kernel's 19 (round 4)
+            const int tot = (int)sum_across_rows(row16_sum((float)cnt));
+            if (tot <= k) res = cand;
         }
         const uint32_t u = (res & 0x80000000u) ? (res & 0x7fffffffu) : ~res;
         if (lane == 0) thr_s = __uint_as_float(u);

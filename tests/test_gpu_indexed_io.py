@@ -106,6 +106,36 @@ def test_copy_indices(dev, dtype):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["normal", "ties", "tiny", "zeros"])
+def test_topk_delta_threshold_shortcut_is_bit_identical(dev, dtype, kind):
+    """The fused kernel decides the low (always-zero) key bits of a 16-bit |delta| in one bisection round; the unfused
+    topk_indices on the eager |delta| runs all 32.  Same threshold -> same indices, including ties at the threshold,
+    subnormal deltas and an all-zero sample."""
+    B, R, C = 1, 5, 4096
+    g = torch.Generator().manual_seed(7)
+    b = torch.randn(B, R, C, generator=g)
+    if kind == "ties":
+        d = torch.randint(0, 4, (B, R, C), generator=g).float() * 0.25
+    elif kind == "tiny":
+        d = torch.randn(B, R, C, generator=g) * 1e-7
+    elif kind == "zeros":
+        d = torch.zeros(B, R, C); d[..., 2048:] = torch.randn(B, R, 2048, generator=g)
+    else:
+        d = torch.randn(B, R, C, generator=g) * 0.3
+    b = b.to(dtype).to(dev)
+    cache0 = (b.float().cpu() + d).to(dtype).to(dev)
+    mdiff = (b - cache0).abs()
+    i1 = torch.full((B, R, C), -9, dtype=torch.int32, device=dev); c1 = torch.zeros(B, R, dtype=torch.int32, device=dev)
+    i2 = torch.full_like(i1, -9); c2 = torch.zeros_like(c1)
+    torch.ops.chipmunk.topk_indices(mdiff, i1, c1, 0.7, 64, 0.0)
+    torch.ops.chipmunk.topk_delta_indices(b, cache0.clone(), i2, c2, 0.7, 64, 0.0)
+    assert torch.equal(c1, c2) and torch.equal(i1, i2)
+    ri = torch.full((B, R, C), -9, dtype=torch.int32); rc = torch.zeros(B, R, dtype=torch.int32)
+    oracle.topk_indices(mdiff.cpu(), ri, rc, 0.7, 64, 0.0)
+    assert torch.equal(rc, c2.cpu()) and torch.equal(ri, i2.cpu())
+
+
 @pytest.mark.parametrize("sparsity,multiple_of,rk", [(0.7, 256, 0.0), (0.85, 112, 0.0), (0.7, 256, 0.05)])
 def test_topk_delta_indices_equals_unfused_sequence(dev, sparsity, multiple_of, rk):
     """fused |b - cache| -> topk_indices -> copy_indices == the three separate ops (reference modules/mlp.py:70-85)."""

@@ -7,7 +7,7 @@ cases=$1; shift
 for rep in 1 2 3; do
   for t in "$@"; do
     if [ "$t" = cur ]; then cp /tmp/cur.so $L; else cp $t $L; fi
-    for c in $cases; do timeout 300 python tools/kbench.py $c $KB_ARGS 2>/dev/null | grep " us " | sed "s|^|$(basename $t)  |"; done
+    for c in $cases; do timeout 300 python tools/kbench.py $c $KB_ARGS 2>/dev/null | grep " us" | sed "s|^|$(basename $t)  |"; done
   done
 done
 cp /tmp/cur.so $L
