@@ -1185,7 +1185,7 @@ extern "C" int chipmunk_dense_colsum_topk_mask_strided(const void *q, const void
     if (!part) return CHIPMUNK_ERR_UNSUPPORTED;
     if (int e = chipmunk_dense64_colsum_launch(p, part, st)) return e;
     const int nrb = ((Nq + 255) / 256) * 4;
-    return chipmunk_topk_mask_parts(part, nrb, p.G, Nq, static_mask, static_stride, static_rows, group_flags, mask, B * H * p.G, Nk,
+    return chipmunk_topk_mask_parts(part, chipmunk_colsum_part_stride(Nk), nrb, p.G, Nq, static_mask, static_stride, static_rows, group_flags, mask, B * H * p.G, Nk,
                                     topk, random_amount, st);
 }
 

@@ -31,6 +31,8 @@ constexpr int TB = KT * HD * 2;           // 16 KiB per K or V tile
 constexpr int NSL = 4;                    // ring slots, K and V each
 constexpr int VRING = NSL * TB;           // byte offset of the V ring
 constexpr int LDS_BYTES = 2 * NSL * TB;   // 128 KiB
+constexpr int PSTAGE = 64 * 128;          // MODE 3: a wave's bf16 P tile [64 queries][64 keys] for the column sums on the matrix pipe
+constexpr int LDS_BYTES_CSUM = LDS_BYTES + 4 * PSTAGE;   // 160 KiB: all of a CU's LDS
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
 // timing ablations (tools/attn64_ablate.py builds one library per value; results are wrong, only the clock is read):
@@ -44,12 +46,29 @@ constexpr float MAX_LAG = 4.0f;
 #ifndef A64_EA
 #define A64_EA 35   // (20 / 35 / 9: with the fixed reference point the first gaps of the PV phase carry no maxima and take nine steps)
 #endif
+#ifndef A64_CSUM_VALU   // 0 = the unit-weight column sums over the matrix pipe (LDS transpose + 16x16x32 MFMAs against ones) instead of the VALU / DPP
+#define A64_CSUM_VALU 1  // reduce-scatter: measured SLOWER (36.3 / 37.3 vs 35.9 ms at 6 heads; see finish_step), kept for tools/attn64_prof.py --mx
+#endif
 #ifndef A64_VSPREAD   // V^T fragment reads: 0 = one per gap in phase A gaps 0..15, 1 = every other gap 0..30
 #define A64_VSPREAD 0
 #endif
 #ifndef A64_DMA_POS   // where the eight DMA pieces of a tile are issued: 0 = phase A gaps 0..7, 1 = phase B gaps 16..30 (even), 2 = phase A gaps
 #define A64_DMA_POS 2  // 16..30 (even; after the V^T reads: 2 718 vs 2 798 cycles per tile for position 0, tools/attn64_cycles.py)
 #endif
+
+// the softmax pipeline's step table: elements exponentiated before step k (steps 0..19 = phase B gaps 12..31, 20..51 = the next
+// phase A, 52.. = the phase B after it), the step that packs bf16 pair j, and the first read step of key unit u of the column sums
+constexpr int a64_ecum(int k) {
+    return k <= 0 ? 0 : k <= 20 ? (k * A64_EB) / 20 : k <= 52 ? A64_EB + ((k - 20) * A64_EA) / 32
+                                                              : (A64_EB + A64_EA + (k - 52) < 64 ? A64_EB + A64_EA + (k - 52) : 64);
+}
+constexpr int a64_cstep(int j) {
+    int k = 0;
+    while (a64_ecum(k) < 2 * j + 2) ++k;
+    return k;
+}
+constexpr int a64_rk(int u) { return u == 0 ? 36 : u == 1 ? 38 : u == 2 ? 68 : 70; }   // reads: phase A / B gaps 16..19
+constexpr int a64_mk(int u) { return u == 0 ? 46 : u == 1 ? 48 : u == 2 ? 78 : 80; }   // MFMAs: gaps 26..29, ~450 cycles behind the reads
 
 #ifdef ATTN64_PROF
 // cycle anatomy (tools/attn64_prof.py builds a separate library with -DATTN64_PROF): s_memtime at the segment boundaries
@@ -356,7 +375,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float wq[2] = {0.f, 0.f}, lpq[2] = {-1.0e30f, -1.0e30f}, c4[2] = {0.f, 0.f}, c5 = 0.f;
     uint32_t csoff = 0;
     __amdgpu_buffer_rsrc_t prsrc = krsrc;
+    // unit-weight loop: the column sums go over the matrix pipe (below).  pst_w / pst_r: this lane's write / read address for
+    // key unit 0 inside the wave's P stage, csf: the fragment reads in flight, csacc / csout: one unit's sums / the tile's
+    uint32_t pst_w = 0, pst_r = 0, csoff_mx = 0;
+    u32x2 csf[8] = {};
+    f32x4 csacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float csout = 0.f;
+    u32x4 cs_ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     if constexpr (CSUM) {
+        pin(cs_ones);
+        const uint32_t pst = lds0 + LDS_BYTES + (uint32_t)w * PSTAGE;
+        pst_w = pst + l31 * 128 + ((uint32_t)(hf ^ (l31 & 7)) << 4);
+        const int prow = lg * 4 + (l15 >> 2);
+        pst_r = pst + prow * 128 + ((uint32_t)(((l15 & 3) >> 1) ^ (prow & 7)) << 4) + (l15 & 1) * 8;
+        csoff_mx = 2u * (uint32_t)(16 * lg + 8 * ((l15 >> 2) & 1) + 4 * (l15 >> 3) + (l15 & 3));
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const int qrow = row0 + qb * 32 + l31;
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the lane that ends up with key row (kb, u, rr, hf) of the tile: kb = bit 0, u = bit 1, rr = bits 4 3 2 (lsb first)
         const int rr = ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2);
         csoff = 2u * (uint32_t)(32 * (lane & 1) + (rr & 3) + 8 * (2 * ((lane >> 1) & 1) + (rr >> 2)) + 4 * hf);
-        prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 4) + (g * 4 + w)) * p.Nk);
+        prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 4) + (g * 4 + w)) * p.cs_pstride);
     }
     // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
 #pragma unroll
@@ -394,10 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //      Slab deadlines (first PV MFMA that reads the fragment): slab 0 at B(t+1) gap 0 (packed by k = 17), slab 1 at gap 8
     //      (k = 31), slab 2 at gap 16 (k = 44), slab 3 at gap 24 (k = 57 = gap 5).
     static_assert(64 - A64_EB - A64_EA >= 0 && 64 - A64_EB - A64_EA <= 9, "the last steps must finish before gap 12 of the next PV phase");
-    auto ecum = [](int k) constexpr {
-        return k <= 0 ? 0 : k <= 20 ? (k * A64_EB) / 20 : k <= 52 ? A64_EB + ((k - 20) * A64_EA) / 32
-                                                                  : (A64_EB + A64_EA + (k - 52) < 64 ? A64_EB + A64_EA + (k - 52) : 64);
-    };
+    auto ecum = [](int k) constexpr { return a64_ecum(k); };
     auto finish_step = [&](auto kk, auto uwc) __attribute__((always_inline)) {
         constexpr int K = decltype(kk)::value;
         constexpr bool UW = decltype(uwc)::value != 0;   // CSUM with unit weights (reference point = the previous step's normaliser)
@@ -418,13 +447,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1] = pack_bf16x2(px[I], px[I + 1]);
                 pin(pw[(I >> 3) & 1][I >> 4][(I & 7) >> 1]);
             });
-            if constexpr (CSUM) {
+            if constexpr (CSUM && UW && !A64_CSUM_VALU) {
+                // Column sums on the matrix pipe (round 4).  With unit weights the summand IS the bf16 P^T the PV MFMAs consume, but
+                // its fragments hold the queries across lanes and the keys in registers -- the contraction index of every MFMA
+                // layout -- so the sum over queries took 102 VALU / DPP operations per tile (~400 of a tile's ~3 100 cycles; the
+                // loop is issue-bound).  Instead: every finished fragment pw[qb][u] (query l31 + 32 qb, the 8 keys of 16-key unit u
+                // this lane half owns) goes into the wave's [64 queries][128 B] stage as one ds_write_b128 (16-byte chunk
+                // (u, hf) stored at chunk ^ (row & 7): conflict-free for the 8-lane groups of the store and the 32-lane groups of
+                // the reads); per unit four ds_read_b64_tr_b16 bring back B fragments (n = key column l15, k = 8 queries) and two
+                // v_mfma_f32_16x16x32_bf16 against an all-ones A sum the 64 queries: every row of D is the unit's 16 column sums,
+                // lane group lg keeps unit lg.  8 stores + 16 reads + 8 MFMAs (128 cycles of the pipe) + 3 selects per tile.
+                // The stage is wave-private: LDS executes a wave's operations in order, no barrier.  Schedule (steps K of the
+                // tile's pipeline; A gaps 16.. and B gaps 16.. carry no other LDS reads, so the lgkmcnt(0) in front of a unit's
+                // MFMAs, four gaps behind its reads, finds them landed):
+                //   store of pw[qb][u]: the step after its last pair is packed;   units 0, 1: reads in phase A gaps 16..19, MFMAs in
+                //   gaps 26..29;   units 2, 3: the same gaps of phase B;   selects three steps behind;   bf16 store in phase B gap 31.
+                // MEASURED (round 4, tools/attn64_prof.py --colsum [--mx]): slower than the reduce-scatter it replaces -- 3 840 vs 3 791
+                // cycles per tile in the marked build, 36.3-37.3 vs 35.9 ms per 6-head launch.  The loop has no idle resource to move
+                // the work to: a ds_write_b128 costs ~33 cycles of the wave's issue time here (phase B gaps 0..11: +66 cycles for two),
+                // the transpose reads ~20 each, and the 16-cycle MFMAs land on a pipe that is 82 % busy in these phases.  Not the default.
+                static_assert(a64_cstep(8 * 1 + 7) + 1 < a64_rk(0) && a64_cstep(8 * 3 + 7) + 1 < a64_rk(2), "a unit is read after its second fragment is stored");
+                static_for<0, 4>([&](auto uu) {
+                    constexpr int U = decltype(uu)::value, S = (U & 1) * 4;
+                    if constexpr (K == a64_mk(U) || K == a64_mk(U) + 1) {
+                        constexpr int H2 = K - a64_mk(U);
+                        if constexpr (H2 == 0 && (U & 1) == 0)
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(csf[0]), "+v"(csf[1]), "+v"(csf[2]), "+v"(csf[3]), "+v"(csf[4]), "+v"(csf[5]), "+v"(csf[6]), "+v"(csf[7]) :: "memory");
+                        const u32x4 fr = {csf[S + 2 * H2][0], csf[S + 2 * H2][1], csf[S + 2 * H2 + 1][0], csf[S + 2 * H2 + 1][1]};
+                        // (asm: the compiler would put the builtin's result into the accumulator file, which here is O^T's; the
+                        // result is read two gaps later, the chained one a gap later: no software wait states needed)
+                        if constexpr (H2 == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(csacc[U & 1]) : "v"(cs_ones), "v"(fr));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(csacc[U & 1]) : "v"(cs_ones), "v"(fr));
+                    }
+                    if constexpr (K == a64_mk(U) + 3) {
+                        if constexpr (U == 0) csout = csacc[0][0];
+                        else csout = lg == U ? csacc[U & 1][0] : csout;
+                        pin(csout);
+                    }
+                    if constexpr (K == a64_rk(U) || K == a64_rk(U) + 1) {
+                        constexpr int H2 = K - a64_rk(U);
+                        uint32_t ad = pst_r;
+                        if constexpr (U != 0) ad ^= (uint32_t)(U << 5);
+                        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
+                                     : "=&v"(csf[S + 2 * H2]), "=&v"(csf[S + 2 * H2 + 1]) : "v"(ad), "i"(H2 * 4096), "i"(H2 * 4096 + 2048) : "memory");
+                    }
+                });
+                static_for<0, 8>([&](auto ii) {
+                    constexpr int U = decltype(ii)::value >> 1, QW = decltype(ii)::value & 1;
+                    if constexpr (K == a64_cstep(8 * U + 4 * QW + 3) + 1) {
+                        uint32_t ad = pst_w;
+                        if constexpr (U != 0) ad ^= (uint32_t)(U << 5);
+                        const u32x4 pf = {pw[QW][U][0], pw[QW][U][1], pw[QW][U][2], pw[QW][U][3]};
+                        asm volatile("ds_write_b128 %0, %1 offset:%c2" ::"v"(ad), "v"(pf), "i"(QW * 4096) : "memory");
+                    }
+                });
+            } else if constexpr (CSUM) {
                 // column sums, in place in px once E / L / C are done with an element (three steps behind E): the weighted sum
                 // over the two query blocks lands in the qb = 1 element of each key, then the reduce-scatter over the 32 lanes
                 // of a half (a step per level), the four slab nodes (px[8], px[24], px[40], px[56]) -> c4 -> c5
                 static_for<ecum(K - 3), ecum(K - 2)>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
                     if constexpr (UW) {
+                        // (v_pk_add_f32 for the two keys of a pair halves this level's operations but returned wrong LOW halves in some
+                        // tile slots -- compiler-emitted and asm alike, with plain adds in the same place the sums are right -- and the
+                        // build with it was 3.6 % slower: round 4, not pursued)
                         if constexpr (((I >> 3) & 1) == 1) { px[I] += px[I - 8]; pin(px[I]); }
                     } else {
                         if constexpr (((I >> 3) & 1) == 0) px[I] *= wq[0];
@@ -521,14 +607,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int up = G >> 3, db = (G >> 1) & 3, qb = G & 1;
             const u32x4 pf = {pw[qb][up][0], pw[qb][up][1], pw[qb][up][2], pw[qb][up][3]};
             mfma_pv<qb, db>(vf[G >> 1], pf);
-            if constexpr (G < (CSUM ? 17 : 12)) finish_step(ic<52 + G>{}, uwc);
-            if constexpr (CSUM && G == 17) {
+            constexpr bool UWT = decltype(uwc)::value != 0 && !A64_CSUM_VALU;
+            if constexpr (G < (CSUM ? (UWT ? 32 : 17) : 12)) finish_step(ic<52 + G>{}, uwc);
+            if constexpr (CSUM && G == (UWT ? 31 : 17)) {
                 // tile t-1's 64 column sums over this wave's 64 queries: one dword per lane into the wave's partial row (a ragged
                 // last tile stores only its own keys, a padding tile nothing)
                 const int tb1 = tile_base(t - 1), dd = (t - 1) * KT - tb1;
                 if (t > 0 && dd < KT) {
-                    if (dd <= 0 || (int)(csoff >> 1) >= dd)
-                        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pack_bf16x2(c5, 0.f) & 0xffffu), prsrc, csoff, (uint32_t)tb1 * 2u, 0);
+                    const uint32_t off = UWT ? csoff_mx : csoff;
+                    if (dd <= 0 || (int)(off >> 1) >= dd)
+                    {
+                        const uint16_t val = (uint16_t)(pack_bf16x2(UWT ? csout : c5, 0.f) & 0xffffu);
+                        if (p.probe & 16) __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb1 * 2u, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb1 * 2u, 0);
+                    }
                 }
             }
             if constexpr (!(A64_ABL & 16) && !GATHER && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
@@ -980,8 +1072,9 @@ template <int MODE>
 int launch64(const AttnParams &p, int64_t grid, hipStream_t stream) {
     auto kern = attn64_kernel<MODE>;
     static uint64_t lds_set = 0;
-    ensure_dynamic_lds((const void *)kern, LDS_BYTES, lds_set);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
+    constexpr int LDS = (MODE == 3 && !A64_CSUM_VALU) ? LDS_BYTES_CSUM : LDS_BYTES;
+    ensure_dynamic_lds((const void *)kern, LDS, lds_set);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -1029,9 +1122,9 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
 // were 21 GB of traffic each way at HunyuanVideo size) and cs_combine_kernel -- or the top-k mask kernel itself, when the
 // caller only wants the mask -- adds the three rows of a group in fp32 (fixed order: the result does not depend on scheduling).
 namespace {
-__global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
+__global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, int pstride, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
     const int g = blockIdx.y, bh = blockIdx.z;
-    const uint16_t *src = part + ((int64_t)bh * NRB + 3 * g) * Nk;
+    const uint16_t *src = part + ((int64_t)bh * NRB + 3 * g) * pstride;
     uint16_t *dst = cs + ((int64_t)bh * G + g) * cs_stride;
     const int nrows = min(3, min(NRB - 3 * g, (Nq - 3 * g * 64 + 63) / 64));
     if (((Nk | cs_stride) & 3) == 0) {
@@ -1044,7 +1137,7 @@ __global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, u
             acc[2] = __uint_as_float(x[1] << 16), acc[3] = __uint_as_float(x[1] & 0xffff0000u);
         }
         for (int r = 1; r < nrows; ++r) {
-            const u32x2 x = *(const u32x2 *)(src + (int64_t)r * Nk + j);
+            const u32x2 x = *(const u32x2 *)(src + (int64_t)r * pstride + j);
             acc[0] += __uint_as_float(x[0] << 16), acc[1] += __uint_as_float(x[0] & 0xffff0000u);
             acc[2] += __uint_as_float(x[1] << 16), acc[3] += __uint_as_float(x[1] & 0xffff0000u);
         }
@@ -1054,7 +1147,7 @@ __global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, u
             const int j = (blockIdx.x * 256 + threadIdx.x) * 4 + e;
             if (j >= Nk) return;
             float acc = bf16_bits_to_f32(src[j]);
-            for (int r = 1; r < nrows; ++r) acc += bf16_bits_to_f32(src[(int64_t)r * Nk + j]);
+            for (int r = 1; r < nrows; ++r) acc += bf16_bits_to_f32(src[(int64_t)r * pstride + j]);
             dst[j] = f32_to_bf16_bits(acc);
         }
     }
@@ -1071,21 +1164,24 @@ int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
     return CHIPMUNK_OK;
 }
 
+int chipmunk_colsum_part_stride(int Nk) { return (chipmunk_get_option("attn_cs_probe") & 1) ? Nk : (Nk + 63) & ~63; }
+
 size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk) {
-    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)Nk * sizeof(uint16_t);
+    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)chipmunk_colsum_part_stride(Nk) * sizeof(uint16_t);
 }
 
 int chipmunk_dense64_colsum_launch(const AttnParams &p0, uint16_t *part, hipStream_t stream) {
     AttnParams p = p0;
     const int G192 = p.G;
     p.G = (p.Nq + WGROWS - 1) / WGROWS;
-    p.cs_part = part;
+    p.cs_part = part, p.cs_pstride = chipmunk_colsum_part_stride(p.Nk);
+    if (chipmunk_get_option("attn_cs_probe") & 2) p.probe |= 16;   // non-temporal partial-row stores
     if (chipmunk_get_option("attn_fused_colsum") == 3) p.probe |= 4;   // weighted column sums even where unit weights would do
     p.kmax = chipmunk_knorm_max(p.k, p.ks, p.B, p.H, p.Nk, stream);
     if (int rc = launch64<3>(p, (int64_t)p.B * p.H * p.G, stream)) return rc;
     if (!p.cs) return CHIPMUNK_OK;   // the caller reads the partial rows itself (chipmunk_topk_mask_parts)
     hipLaunchKernelGGL(cs_combine_kernel, dim3((unsigned)((p.Nk + 1023) / 1024), (unsigned)G192, (unsigned)(p.B * p.H)), dim3(256), 0, stream,
-                       part, p.cs, p.G * 4, G192, p.Nq, p.Nk, p.cs_stride);
+                       part, p.cs_pstride, p.cs, p.G * 4, G192, p.Nq, p.Nk, p.cs_stride);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

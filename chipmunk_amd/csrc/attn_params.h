@@ -34,6 +34,7 @@ struct AttnParams {
     const float *kmax;
     // attn64.hip MODE 3 (dense + fused column sums): bf16 partial column sums, one row of Nk per (batch*head, 64-row wave block)
     uint16_t *cs_part;
+    int cs_pstride;  // elements between two of those rows (chipmunk_colsum_part_stride)
     int probe;  // timing probes (tools/kbench.py --variants): 1 = no gathers after the prologue, 2 = gathers only
 };
 
@@ -47,10 +48,13 @@ int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_
 int chipmunk_dense64_colsum_launch(const AttnParams &p, uint16_t *part, hipStream_t stream);
 // indexed_io.hip: the top-k mask straight from the partial rows (row r of the mask = sum of rows 3r .. 3r+2 of `part` in its
 // (batch*head) block of `nrb` rows, rounded to bf16 -- exactly what the combine would have written)
-int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
+int chipmunk_topk_mask_parts(const uint16_t *part, int part_stride, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
                              int static_rows, const void *group_flags, void *mask, int rows, int n, int k, double random_amount,
                              hipStream_t stream);
 size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk);
+// elements between two partial rows: Nk rounded up to whole 128-byte lines, so that a wave's 64 sums of a key tile are ONE
+// aligned line (a row of 119 056 keys is 1 860.25 lines: at stride Nk every store straddled two)
+int chipmunk_colsum_part_stride(int Nk);
 // attn64.hip: the column-sum pass of dense_colsum_attn for long launches (one wave per 192-row group)
 int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
 // attn96.hip: gathered attention, two waves x 96 rows per 192-row group, two workgroups per CU (plan as for csp64)

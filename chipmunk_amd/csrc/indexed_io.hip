@@ -577,6 +577,7 @@ struct TopkMaskParams {
     uint32_t salt;           // per-launch value, see chipmunk_next_random_salt
     // PARTS form: row r of "cs" = bf16(sum of rows 3g .. 3g+2 of the partial rows of its (batch*head) block), g = r % groups
     const uint16_t *parts;
+    int64_t pstride;         // elements between two partial rows
     int nrb, ngroups, nq;    // partial rows per (batch*head); 192-row groups per (batch*head); query rows
 };
 
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     int prow = 1;
     if constexpr (PARTS) {
         const int bh = row / p.ngroups, g = row - bh * p.ngroups;
-        x = p.parts + ((int64_t)bh * p.nrb + 3 * g) * n;
+        x = p.parts + ((int64_t)bh * p.nrb + 3 * g) * p.pstride;
         prow = min(3, min(p.nrb - 3 * g, (p.nq - 3 * g * 64 + 63) / 64));
     } else {
         x = p.cs + (int64_t)row * p.cs_stride;
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
                         float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
                         float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
                         for (int r = 1; r < prow; ++r) {
-                            const u32x2 y = *(const u32x2 *)((const unsigned char *)(x + (int64_t)r * n + 4096 * (j0 + jj)) + lane_off8);
+                            const u32x2 y = *(const u32x2 *)((const unsigned char *)(x + (int64_t)r * p.pstride + 4096 * (j0 + jj)) + lane_off8);
                             a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
                             a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
                         }
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
             float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
             float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
             for (int r = 1; r < prow; ++r) {
-                const u32x2 y = *(const u32x2 *)(x + (int64_t)r * n + c0);
+                const u32x2 y = *(const u32x2 *)(x + (int64_t)r * p.pstride + c0);
                 a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
                 a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
             }
@@ -972,10 +973,10 @@ extern "C" int chipmunk_gather_rows(const void *src, void *dst, const int32_t *m
     return CHIPMUNK_OK;
 }
 
-int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
+int chipmunk_topk_mask_parts(const uint16_t *part, int part_stride, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
                              int static_rows, const void *group_flags, void *mask, int rows, int n, int k, double random_amount,
                              hipStream_t s) {
-    CM_CHECK(part && mask && rows >= 0 && n > 0 && (n & 3) == 0 && n <= 1024 * 120 && k >= 0, "topk_mask_parts: bad arguments");
+    CM_CHECK(part && mask && rows >= 0 && n > 0 && (n & 3) == 0 && n <= 1024 * 120 && k >= 0 && part_stride >= n && (part_stride & 3) == 0, "topk_mask_parts: bad arguments");
     CM_CHECK(!static_mask || (static_rows > 0 && static_stride >= n && (static_stride & 3) == 0 && ((uintptr_t)static_mask & 3) == 0),
              "topk_mask_parts: bad static mask geometry");
     CM_CHECK(((uintptr_t)mask & 3) == 0 && ((uintptr_t)part & 7) == 0, "topk_mask_parts: unaligned buffers");
@@ -983,7 +984,7 @@ int chipmunk_topk_mask_parts(const uint16_t *part, int nrb, int groups_per_bh, i
     TopkMaskParams p = {nullptr, (const uint8_t *)static_mask, (const uint8_t *)group_flags, (uint8_t *)mask, 0, static_stride,
                         rows, n, k, static_mask ? static_rows : 1, (float)random_amount,
                         random_amount > 0.0 ? chipmunk_next_random_salt() : 0u};
-    p.parts = part, p.nrb = nrb, p.ngroups = groups_per_bh, p.nq = Nq;
+    p.parts = part, p.pstride = part_stride, p.nrb = nrb, p.ngroups = groups_per_bh, p.nq = Nq;
     if (n <= 1024 * 16) hipLaunchKernelGGL((topk_mask_kernel<16, true, true>), dim3(rows), dim3(1024), 0, s, p);
     else if (n <= 1024 * 48) hipLaunchKernelGGL((topk_mask_kernel<48, true, true>), dim3(rows), dim3(1024), 0, s, p);
     else hipLaunchKernelGGL((topk_mask_kernel<120, true, true>), dim3(rows), dim3(1024), 0, s, p);

@@ -48,7 +48,6 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // evaluated as x - x / (1 + exp2(x * (GA + GB x^2))).  The 2-wide form is the same operation sequence on v_pk_*_f32 (the epilogue
 // is VALU-bound: tools/mlp_prof.py, 18 k of a tile's 103 k cycles before this form), element-for-element the same bits.
 constexpr float GELU_A = 0.7978845608028654f * 2.0f * 1.44269504089f, GELU_B = GELU_A * 0.044715f;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t pack_bf16x2_v(f32x2 v) { return pack_bf16x2(v[0], v[1]); }   // v_cvt_pk_bf16_f32, RNE
 __device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ float gelu_tanh(float x) {

@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmark at the BASELINE shapes: back-to-back launches inside one HIP-event bracket, so the
 number is kernel time (comparable with rocprofv3's average duration), not host launch latency.
 
-usage: python tools/kbench.py [mm1 mm1s mm2 scatter csp_flux csp_hunyuan dense_flux colsum_flux topk m2i copy] [--variants 0,1,2]
+usage: python tools/kbench.py [mm1 mm1s mm2 scatter csp_flux csp_hunyuan dense_flux colsum_flux maskstep_hunyuan topk m2i copy] [--variants 0,1,2]
 """
 import argparse
 import os
@@ -189,6 +189,12 @@ def bench_attn(which, variants):
         elif which.startswith("colsum"):
             _, l = torch.ops.chipmunk.dense_attn(q, k, v)
             ms = timeit(lambda: torch.ops.chipmunk.dense_colsum_attn(q, k, v, l), reps=5)
+            flops = 4.0 * H * N * N * 128
+        elif which.startswith("maskstep"):
+            # the mask-recompute step's attention: dense + column sums + top-k mask in one op (7 % of the keys kept)
+            _, l = torch.ops.chipmunk.dense_attn(q, k, v)
+            ktop = int(os.environ.get("KB_KTOP", str(int(0.07 * N))))
+            ms = timeit(lambda: torch.ops.chipmunk.dense_colsum_topk_mask(q, k, v, l, ktop, 0.0, None, None, False), reps=5)
             flops = 4.0 * H * N * N * 128
         elif which.startswith("sdpa"):
             ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v), reps=5)
