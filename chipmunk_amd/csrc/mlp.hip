@@ -167,17 +167,26 @@ struct Mm1Params {
 // (TM/2) x (TN/2) accumulator of 32x32x16 MFMA tiles; NST-deep LDS ring of [A tile | B tile] stages.
 // FP8: operands are OCP e4m3 bytes (BASELINE config C5; reference src/chipmunk/triton/csp_mlp_mm1.py:37-164); BK then
 // still counts 2-byte units, i.e. a k step is BK*2 = 128 bytes of every row either way.
-template <int TM, int TN, int BK, int NST, bool FP8 = false>
+// NW = 8 (round 4, option mm1_variant = 10; NOT the default): the same 64 x 64 accumulator per wave, 2 x 4 waves over a 128 x 256 tile -- two
+// waves per SIMD out of ONE workgroup per CU instead of two 128 x 128 workgroups: 48 KiB instead of 64 KiB through the L2 -> LDS path per
+// 128 x 256 outputs and k step, three stages in 144 KiB.  MEASURED SLOWER: 145-149 vs 117-125 us (FLUX bf16), 231-234 vs 206-222 us
+// (Wan fp8), tools/mlp_prof.py: 2 000 ticks per k step against 1 620 for the PAIR of 128 x 128 workgroups, and an epilogue of 12.8 k
+// ticks that nothing overlaps (two independent workgroups run one's epilogue under the other's k loop; here all eight waves sit in it).
+// Neither the second wave of a SIMD issuing its DMA pieces after its MFMAs (2 200 per step) nor the pieces spread between the MFMA
+// groups (no change; the 4-wave form 125 -> 131 us bf16, 219 -> 212 us fp8, inside box noise) helps: the loop waits on the
+// landing of the gathered rows, not on their bytes or their issue.
+template <int TM, int TN, int BK, int NST, bool FP8 = false, int NW = 4>
 __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem, int g, int m_off, int n0, int cnt) {
     using KT = KTile<BK>;
     constexpr uint32_t ESZ = FP8 ? 1u : 2u;  // operand element size in bytes
     constexpr int A_TILE = TM * BK * 2, B_TILE = TN * BK * 2, STAGE = A_TILE + B_TILE;
-    constexpr int A_INST = A_TILE / 4096, B_INST = B_TILE / 4096;  // DMA instructions per wave per tile
-    constexpr int MT = TM / 64, NT4 = TN / 64;                      // 32-wide m / n tiles per wave
+    constexpr int A_INST = A_TILE / (1024 * NW), B_INST = B_TILE / (1024 * NW);  // DMA instructions per wave per tile
+    constexpr int WNC = NW / 2;                                     // waves across the tile's columns (2 down its rows)
+    constexpr int MT = TM / 64, NT4 = TN / (32 * WNC);              // 32-wide m / n tiles per wave
     static_assert(A_INST >= 1 && B_INST >= 1, "tile too small for one DMA instruction per wave");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WNC, wn = w % WNC;
     const int32_t *idxg = p.indices + (int64_t)g * p.F;
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a), rb = make_rsrc(p.b);
@@ -206,10 +215,14 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     // the LAST k step into the stage no tile needs any more, and the bf16 results leave through the other stage as
     // 16-byte row-major stores.  (Direct form: 8-byte gathered loads and 2-byte stores, 64 of each per lane --
     // measured 34 us of a 148 us launch.)
-    constexpr bool STAGED = TM * TN * 2 <= STAGE;
+    // FLAT (tiles whose outputs exceed one stage): the ring starts at the stage that makes the LAST k step compute out of stage 0, the
+    // cache block lands behind it in [STAGE, STAGE + TM*TN*2) and the outputs leave through stage 0 plus the bytes behind the cache block.
+    constexpr int EPI = TM * TN * 2;
+    constexpr bool FLAT = NW == 8 && EPI > STAGE && EPI <= (NST - 1) * STAGE && 2 * EPI <= NST * STAGE && STAGE % (TN * 2) == 0;
+    constexpr bool STAGED = EPI <= STAGE || FLAT;
     static_assert(!FP8 || STAGED, "the fp8 form is only built for tile shapes with the staged epilogue");
     constexpr int LPR = TM * 2 / 16;                                  // 16-byte chunks per cache row
-    constexpr int C_INST = STAGED ? TM * TN * 2 / 4096 : 1;           // DMA instructions per wave
+    constexpr int C_INST = STAGED ? EPI / (1024 * NW) : 1;            // DMA instructions per wave
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.cache);
     uint32_t coff[C_INST];
     if constexpr (STAGED) {
@@ -224,7 +237,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     auto issue_cache = [&](int buf) {
         if constexpr (STAGED) {
 #pragma unroll
-            for (int i = 0; i < C_INST; ++i) blds16(rc, coff[i], 0, smem + buf * STAGE + (w * C_INST + i) * 1024);
+            for (int i = 0; i < C_INST; ++i) blds16(rc, coff[i], 0, smem + (FLAT ? STAGE : buf * STAGE) + (w * C_INST + i) * 1024);
         }
     };
 
@@ -236,7 +249,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     f32x16 acc[MT][NT4];
 #pragma unroll
     for (int n4 = 0; n4 < NT4; ++n4) {
-        const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
+        const int j = n0 + wn * (TN / WNC) + n4 * 32 + (lane & 31);
         bias_v[n4] = bf16_bits_to_f32(p.bias[idxg[j < cnt ? j : n0]]);
         const float seed = SEED_BIAS ? bias_v[n4] : 0.f;
 #pragma unroll
@@ -246,10 +259,11 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     }
 
     const int nkb = (int)((uint32_t)p.K * ESZ / (BK * 2));
+    int buf = FLAT ? (NST - (nkb - 1) % NST) % NST : 0;   // FLAT: k step nkb-1 computes out of stage 0
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-        if (s < nkb) issue(s, s);
-    int buf = 0, nbuf = NST - 1;
+        if (s < nkb) issue(s, (buf + s) % NST);
+    int nbuf = (buf + NST - 1) % NST;
     MPROF_DECL;
     MPROF_ABS(1);
     MPROF_START();
@@ -295,7 +309,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[set][mt] = frag(At, wm * (TM / 2) + mt * 32 + (lane & 31), kk);
 #pragma unroll
-            for (int n4 = 0; n4 < NT4; ++n4) bfr[set][n4] = frag(Bt, wn * (TN / 2) + n4 * 32 + (lane & 31), kk);
+            for (int n4 = 0; n4 < NT4; ++n4) bfr[set][n4] = frag(Bt, wn * (TN / WNC) + n4 * 32 + (lane & 31), kk);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -336,7 +350,9 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         // after the loop: buf = stage after the last computed one = the cache stage (NST = 2) or a free one
         const int last = buf == 0 ? NST - 1 : buf - 1;                  // stage of tile nkb-1
         const int cst = last + NST - 1 >= NST ? last - 1 : last + NST - 1;  // nbuf at kb = nkb-1
-        unsigned char *Ct = smem + cst * STAGE, *Ot = smem + last * STAGE;
+        unsigned char *Ct = smem + (FLAT ? 1 : cst) * STAGE, *Ot = smem + (FLAT ? 0 : last) * STAGE;
+        // output row r of the stage image (FLAT: the rows that do not fit stage 0 continue behind the cache block)
+        auto ot_row = [&](int r) { return Ot + r * (TN * 2) + ((FLAT && r >= STAGE / (TN * 2)) ? EPI : 0); };
         constexpr int LPO = TN * 2 / 16;  // 16-byte chunks per output row
         wait_vmcnt<0>();
         __syncthreads();  // cache block landed; every wave is done reading the last tile
@@ -345,7 +361,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         // of a read hit 32 rows of the [column][m] image at one m).  Two values per instruction wherever the ISA has a packed form.
 #pragma unroll
         for (int n4 = 0; n4 < NT4; ++n4) {
-            const int jl = wn * (TN / 2) + n4 * 32 + (lane & 31);
+            const int jl = wn * (TN / WNC) + n4 * 32 + (lane & 31);
             const float bia = bias_v[n4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -369,7 +385,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
                         // the bias is already in the sum (SEED_BIAS)
                         d01 = pack_bf16x2_v(gelu_tanh2(a01) - c01), d23 = pack_bf16x2_v(gelu_tanh2(a23) - c23);
                     }
-                    uint16_t *op = (uint16_t *)(Ot + ml * (TN * 2) + jl * 2);
+                    uint16_t *op = (uint16_t *)(ot_row(ml) + jl * 2);   // (rows ml .. ml+3: on one side of the split, a multiple of 4)
                     op[0] = (uint16_t)d01, op[TN] = (uint16_t)(d01 >> 16), op[2 * TN] = (uint16_t)d23, op[3 * TN] = (uint16_t)(d23 >> 16);
                     if (p.update_cache) {
                         // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
@@ -381,11 +397,11 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
             }
         }
         __syncthreads();
-        constexpr int O_INST = TM * TN * 2 / 4096;  // 1 KiB row-major pieces per wave
+        constexpr int O_INST = EPI / (1024 * NW);  // 1 KiB row-major pieces per wave
 #pragma unroll
         for (int i = 0; i < O_INST; ++i) {
             const int r = (w * O_INST + i) * (64 / LPO) + lane / LPO, ch = lane % LPO;
-            const u32x4 v = *(const u32x4 *)(Ot + r * (TN * 2) + (ch << 4));
+            const u32x4 v = *(const u32x4 *)(ot_row(r) + (ch << 4));
             const int j = n0 + ch * 8;
             uint16_t *cp = p.c + (int64_t)(g * BM + m_off + r) * p.F + j;
             if (j + 8 <= cnt && (p.F & 7) == 0) {
@@ -407,7 +423,7 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     } else {
 #pragma unroll
         for (int n4 = 0; n4 < NT4; ++n4) {
-            const int j = n0 + wn * (TN / 2) + n4 * 32 + (lane & 31);
+            const int j = n0 + wn * (TN / WNC) + n4 * 32 + (lane & 31);
             const bool live = j < cnt;
             const int col = live ? idxg[j] : 0;
             const uint16_t *crow = p.cache + (int64_t)col * p.M;
@@ -442,11 +458,11 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     MPROF_END(w, nkb);
 }
 
-template <int BN, int BK, int NST, int WPS, bool FP8 = false>
-__global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
+template <int BN, int BK, int NST, int WPS, bool FP8 = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, WPS) void mm1_kernel(const Mm1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MPROF_ABS(0);
-    constexpr int NSUB = 2 * (BN / 64);  // 64 x 64 sub-tiles per tile
+    constexpr int NSUB = NW == 4 ? 2 * (BN / 64) : 1;  // 64 x 64 sub-tiles per tile (the 8-wave form has no tail split)
     // PERSISTENT workgroups: the grid is the resident slots (WPS per CU); a workgroup walks its XCD's tile list with the stride of the
     // XCD's slots -- the same tile-to-slot order a one-tile-per-workgroup grid is dispatched in, without the relaunch between tiles
     // (kernel arguments, the live-tile map, wave start-up: 5.4 k of a 41 k-cycle tile at the Wan2.1 fp8 shape, tools/mlp_prof.py) and
@@ -462,8 +478,8 @@ __global__ __launch_bounds__(256, WPS) void mm1_kernel(const Mm1Params p) {
         if (tm.sub < 0) {
             const int n0 = tm.nt * BN;
             if (n0 >= cnt) continue;  // tiles past counts[g] are skipped (csp_mlp_mm1.cu:233-243)
-            mm1_tile<BM, BN, BK, NST, FP8>(p, smem, g, 0, n0, cnt);
-        } else {
+            mm1_tile<BM, BN, BK, NST, FP8, NW>(p, smem, g, 0, n0, cnt);
+        } else if constexpr (NW == 4) {
             constexpr int SUB_NST = (NST * (BM + BN)) / 128;  // same LDS bytes, stages of 64 + 64 rows
             const int n0 = tm.nt * BN + (tm.sub >> 1) * 64;
             if (n0 >= cnt || p.probe == 3) continue;  // probe 3: time the launch without its tail
@@ -840,11 +856,12 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
     }
 }
 
-template <int BN, int BK, int NST, int WPS, bool FP8 = false>
+template <int BN, int BK, int NST, int WPS, bool FP8 = false, int NW = 4>
 int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated = nullptr) {
-    constexpr int LDS = NST * (BM * BK * 2 + BN * BK * 2);
-    constexpr bool STAGED = BM * BN * 2 <= (BM + BN) * BK * 2;  // mm1_tile's staged epilogue (the one that can scatter)
-    auto kern = mm1_kernel<BN, BK, NST, WPS, FP8>;
+    constexpr int STAGE = BM * BK * 2 + BN * BK * 2, LDS = NST * STAGE, EPI = BM * BN * 2;
+    // mm1_tile's staged epilogue (the one that can scatter): one stage each for cache block and outputs, or the FLAT layout
+    constexpr bool STAGED = EPI <= STAGE || (NW == 8 && EPI <= (NST - 1) * STAGE && 2 * EPI <= NST * STAGE && STAGE % (BN * 2) == 0);
+    auto kern = mm1_kernel<BN, BK, NST, WPS, FP8, NW>;
     static uint64_t lds_set = 0;
     ensure_dynamic_lds((const void *)kern, LDS, lds_set);
     Mm1Params p = p0;
@@ -855,11 +872,11 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated =
     if (p.NR > p.NT) p.NR = p.NT;
     // tail split: WPS workgroups per CU are resident; an XCD's leftover tiles are handed out as sub-tiles at the end of its list
     const int resident_per_xcd = WPS * device_cu_count() / 8;
-    p.slots_per_xcd = chipmunk_get_option("mm1_no_split") ? 0 : resident_per_xcd;
+    p.slots_per_xcd = (chipmunk_get_option("mm1_no_split") || NW != 4) ? 0 : resident_per_xcd;
     // persistent grid: the resident slots, or fewer when the launch has fewer tiles than slots (every tile gets its own workgroup)
     const int tiles_per_xcd = ((p.M / BM) * p.NT + 7) / 8;
     const int per_xcd = tiles_per_xcd < resident_per_xcd ? tiles_per_xcd : resident_per_xcd;
-    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(NW * 64), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }
@@ -885,6 +902,7 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
         case 7: return launch_mm1_variant<128, 32, 3, 3>(p, stream, cache_updated);
         case 8: return launch_mm1_variant<128, 64, 2, 3>(p, stream, cache_updated);
         case 9: return launch_mm1_variant<128, 64, 2, 4>(p, stream, cache_updated);
+        case 10: return launch_mm1_variant<256, 64, 3, 1, false, 8>(p, stream, cache_updated);
         default: return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*)
     }
 }
@@ -942,5 +960,6 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
     // same tile machinery as the bf16 kernel (buffer-form DMA, tail split, staged epilogue); a k step is 128 fp8 values
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
                    indices, counts, M, K, F, 0, 0, 0, 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
+    if (chipmunk_get_option("mm1_variant") == 10) return launch_mm1_variant<256, 64, 3, 1, true, 8>(p, (hipStream_t)stream);
     return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }
