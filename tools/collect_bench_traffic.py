@@ -30,11 +30,11 @@ WORKLOADS = {
     "hunyuan_c3": (["--steps", "2", "--warmup", "3", "--no-legs", "--dense-steps", "0", "--no-cpu-baseline", "--no-step-caching"], OPS,
                    "bench.py's own launches (hunyuan_c3: 24 heads x 119 056 tokens, ragged module-generated key counts)"),
     "flux_c2": (["--workload", "flux_c2", "--steps", "4", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline"],
-                {"mm1+scatter_add": ["mm1_kernel<128, 64, 2, 2, false>"], "mm2": ["mm2_kernel"], "csp_attn": ["attn_kernel<true, true, false, false>"],
+                {"mm1+scatter_add": ["mm1_kernel<128, 64, 2, 2, false"], "mm2": ["mm2_kernel"], "csp_attn": ["attn_kernel<true, true, false, false>"],
                  "topk_delta_indices": ["topk_indices_kernel"], "block_mean": ["block_mean_kernel"]},
                 "bench.py's own launches (flux_c2: 24 heads x 4 352 tokens, 672 kept keys; MLP 34 / 30 groups, module-generated index lists)"),
     "wan_c5": (["--workload", "wan_c5", "--steps", "2", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline"],
-               {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true>"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"],
+               {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"],
                 "dense_attn_c3_wan": ["attn64_kernel<0>"], "dense_colsum_topk_mask_c3_wan": ["attn64_kernel<3>", "topk_mask_kernel"]},
                "bench.py's own launches (wan_c5: Wan2.1 1.3B shapes, 12 heads x 32 760 tokens, fp8 GEMM1 M 32 768 / K 1 536 / F 8 960)"),
 }
@@ -43,7 +43,7 @@ WORKLOADS = {
 # rocprofv3 --pmc segfaults on the wan_c5 bench itself (ROCm 7.2; the workload's pinned-host copies on side streams): its two GEMM
 # kernels are profiled on tools/kbench.py's launches at the same shapes instead, and the entry says so
 WORKLOADS["wan_c5_kbench"] = (["@kbench", "fp8_wan", "mm2_wan", "csp_hunyuan"],   # (the gathered kernel at 12 heads x 32 760 tokens, 8 832 keys per group: the bench's mean)
-                              {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true>"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"]},
+                              {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"]},
                               "tools/kbench.py launches at the wan_c5 shapes (M 32 768, K 1 536, F 8 960, keep 0.3; same buffers every launch), NOT "
                               "the bench's own launches: rocprofv3 --pmc crashes on that workload")
 
