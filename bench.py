@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument("--no-projections", action="store_true", help="hunyuan: attention + MLP only (round-2 definition of a step)")
     ap.add_argument("--no-fused-rowwise", action="store_true", help="hunyuan / wan: the block's residual + LayerNorm + modulate as torch ops")
     ap.add_argument("--no-legs", action="store_true", help="hunyuan: skip the 82 %%, step-caching and q-scale legs")
+    ap.add_argument("--event-period", type=int, default=0,
+                    help="bracket every n-th call of a timed op with HIP events (default: 1 for hunyuan's ms-scale launches, 7 for flux / wan, "
+                         "where a bracket's ~10 us bubble is 5-10 %% of the launch it measures)")
     ap.add_argument("--qk-scale", type=float, default=4.0, help="hunyuan: q multiplier of the running-maximum-fallback leg")
     ap.add_argument("--sp-no-overlap", action="store_true", help="hunyuan_sp: exchange on the compute stream (reference order)")
     ap.add_argument("--sp-no-exchange", action="store_true", help="hunyuan_sp: compute only (probe for the exposed-comm fraction)")
@@ -102,10 +105,20 @@ class KernelTimer:
         self.last_call = {}
         self.enabled = False
         self.keep_last_call = True   # probe() re-launches the last call; off for workloads whose arguments are GBs
+        # A pair of events around a launch opens a ~10 us bubble behind it (tools/step_timeline.py on the FLUX run: 132 of them = 1.4 ms of a
+        # 28.3 ms step when every call of the three timed ops is bracketed).  period = n brackets every n-th call of an op (n co-prime to the
+        # calls per step, so the sample walks through all layers); the other calls run bare and are only counted.
+        self.period = 1
+        self.calls = {}
 
     def wrap(self, name, fn, work_fn):
         def wrapped(*args, **kwargs):
             if not self.enabled:
+                return fn(*args, **kwargs)
+            n = self.calls[name] = self.calls.get(name, 0) + 1
+            if self.period > 1 and n % self.period != 0 and n != 1:   # (the first call is always bracketed: rarely called ops still appear)
+                if self.keep_last_call:
+                    self.last_call[name] = (fn, args, kwargs, work_fn)
                 return fn(*args, **kwargs)
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
@@ -136,7 +149,8 @@ class KernelTimer:
         for name, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _ in recs]
             work = [w() for _, _, w in recs]
-            out[name] = {"launches": len(recs), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
+            calls = max(self.calls.get(name, len(recs)), len(recs))
+            out[name] = {"launches": calls, "timed_launches": len(recs), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms) / len(ms) * calls,
                          "avg_flops": sum(w[0] for w in work) / len(work), "avg_bytes": sum(w[1] for w in work) / len(work)}
         return out
 
@@ -768,15 +782,15 @@ class Hunyuan:
         """Sparse steps with q multiplied by `scale`: 2 |q| max|k| c exceeds 64, so the gathered kernel cannot prove the fixed
         reference point safe and runs its running-maximum fallback -- the data-dependent slow path made
         driver-visible.  The masks are those of the unscaled run (same key counts, same work)."""
-        before = {k: list(v) for k, v in timer.records.items()}
-        timer.records = {}
+        before, calls_before = {k: list(v) for k, v in timer.records.items()}, dict(timer.calls)
+        timer.records, timer.calls = {}, {}
         timer.enabled = True
         self.q_scale = scale
         times = self.run_steps(12, sparse_steps)
         self.q_scale = 1.0
         timer.enabled = False
         summ = timer.summary().get("csp_128_attn")
-        timer.records = before
+        timer.records, timer.calls = before, calls_before
         return {"q_scale": scale, "sparse_step_s": sum(t for _, _, t in times) / len(times),
                 "csp_128_attn_avg_ms": None if summ is None else round(summ["avg_ms"], 4)}
 
@@ -803,13 +817,13 @@ class Hunyuan:
             b96 = torch.nn.functional.pad(bound, (0, pad)).view(bound.shape[0], bound.shape[1], -1, 96).amax(-1)   # one wave = 96 query rows
             fast.append(float((b96 <= 55.0).float().mean().item()))
             del qn, kmax, bound, b96
-        before = {k_: list(v_) for k_, v_ in timer.records.items()}
-        timer.records = {}
+        before, calls_before = {k_: list(v_) for k_, v_ in timer.records.items()}, dict(timer.calls)
+        timer.records, timer.calls = {}, {}
         timer.enabled = True
         times = self.run_steps(12, sparse_steps)
         timer.enabled = False
         summ = timer.summary().get("csp_128_attn")
-        timer.records = before
+        timer.records, timer.calls = before, calls_before
         self.qkv = saved
         return {"gain_sigma": sigma, "waves_on_the_loop_without_reference_point": sum(fast) / len(fast),
                 "sparse_step_s": sum(t for _, _, t in times) / len(times),
@@ -1171,6 +1185,7 @@ def main():
         args.dense_steps = 1 if hunyuan else 3 if not wan else 2
 
     timer = KernelTimer()
+    timer.period = args.event_period if args.event_period > 0 else (1 if hunyuan else 7)
     wl = None
     if hunyuan:
         wl = Hunyuan(dev, rank, world, args, timer)
@@ -1380,12 +1395,14 @@ def main():
         "data": "synthetic",
         "config": desc,
         "roofline": roof,
-        "kernels": {n: {"launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
+        "kernels": {n: {"launches": k["launches"], "timed_launches": k.get("timed_launches", k["launches"]), "avg_ms": round(k["avg_ms"], 4),
                         "tflops": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 1),
                         "mfma_frac": round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12 / (wan_extra["peak_tflops"].get(n, MFMA_BF16_PEAK_TFS) if wan else MFMA_BF16_PEAK_TFS), 3),
                         "peak_tflops": (wan_extra["peak_tflops"].get(n, MFMA_BF16_PEAK_TFS) if wan else MFMA_BF16_PEAK_TFS),
                         "share_of_kernel_time": round(k["total_ms"] / max(sum(x["total_ms"] for x in kernels.values()), 1e-9), 3),
                         "traffic": pmc_traffic(n)[0]} for n, k in kernels.items()},
+        "event_brackets": {"every_nth_call_of_a_timed_op": timer.period,
+                           "what": "kernels.*.avg_ms are HIP-event brackets on the launch stream inside the timed region; launches = all calls, timed_launches = the bracketed ones"},
         "dense_gpu_comparator": comparator,
         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (
             cpu_baseline_hunyuan(n_layers, wl.N, projections=not args.no_projections) if hunyuan else

@@ -79,6 +79,13 @@ def test_wan_and_flux_lines():
     f = _bench("--workload", "flux_c2", "--layers", "6", "--steps", "6", "--warmup", "12", "--dense-steps", "1")
     _check_common(f, 6, 12)
     assert f["config"]["workload"].startswith("flux_c2") and {"csp_attn", "csp_mlp_mm2"} <= set(f["kernels"])
+    # microsecond-scale launches: only every 7th call of a timed op carries a HIP-event bracket (a bracket's bubble is ~10 us); all calls are counted
+    for line in (w, f):
+        assert line["event_brackets"]["every_nth_call_of_a_timed_op"] == 7
+        for k in line["kernels"].values():
+            assert 1 <= k["timed_launches"] <= k["launches"] and k["timed_launches"] <= k["launches"] // 7 + 1 and k["avg_ms"] > 0
+    g = _bench("--workload", "flux_c2", "--layers", "6", "--steps", "6", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline", "--event-period", "1")
+    assert all(k["timed_launches"] == k["launches"] for k in g["kernels"].values())
 
 
 @pytest.mark.parametrize("mode", ["heads", "groups"])
