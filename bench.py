@@ -1410,6 +1410,24 @@ def main():
     }
     if wan:
         line.update(wan_extra["line"]())
+        if world == 1 and not args.no_legs and not args.offload and os.environ.get("WAN_RESIDENT") != "1":
+            # configs[4] as worded keeps the attention caches in pinned host memory (the reference's shipped Wan config, written for 80 GB
+            # cards).  The same schedule with the residency policy on (offloading.keep_resident_if_fits: 6 GB of caches in 288 GB of HBM, the
+            # kept compact index lists instead of re-deriving them from the packed masks every step), measured by a second process
+            env = dict(os.environ, WAN_RESIDENT="1")
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "wan_c5", "--no-cpu-baseline", "--dense-steps", "0", "--no-legs",
+                   "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--layers", str(args.layers)] if args.layers else [])
+            try:
+                import subprocess
+                torch.cuda.empty_cache()
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                leg = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+                line["resident_leg"] = {"value": leg["value"], "unit": "steps/s", "over_the_offloaded_run": leg["value"] / value,
+                                        "what": "same workload, caches resident in HBM (offloading.keep_resident_if_fits), run as a second process: "
+                                                "without the host copies' blit kernels on the compute queue (5 % of the kernel time) and the contention "
+                                                "they cause, and with the kept compact index lists"}
+            except Exception as e:       # noqa: BLE001
+                line["resident_leg"] = {"error": repr(e)[:200]}
     line.update(extra)
     try:    # 0 in a healthy run: every refused request for the multi-GB column-sum scratch sent a mask step down a slower route
         from chipmunk_amd import _native

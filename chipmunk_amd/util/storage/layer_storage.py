@@ -12,7 +12,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
-from .offloaded_tensor import MaybeOffloadedTensor
+from .offloaded_tensor import MaybeOffloadedTensor, wait_for_side_streams
 
 
 class _NamedStorage:
@@ -46,16 +46,22 @@ class _NamedStorage:
                 holder.complete_cur_layer()
 
     def load_async(self) -> None:
+        # one gate of the load stream on the compute stream for all of the layer's tensors (offloaded_tensor.py's header)
+        gate = True
         for field in self._async_fields:
             holder = getattr(self, field)
             if holder is not None:
-                holder.load_async()
+                copies = holder.needs_host_copy()
+                holder.load_async(gate=gate)
+                gate = gate and not copies
 
     def load_async_wait(self) -> None:
+        # ... and one wait of the compute stream for all of them
         for field in self._async_fields:
             holder = getattr(self, field)
-            if holder is not None:
-                holder.load_async_wait()
+            if holder is not None and holder.waits_on_side_streams():
+                wait_for_side_streams()
+                return
 
 
 def _accessors(cls):

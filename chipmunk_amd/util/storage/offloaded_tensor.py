@@ -9,7 +9,12 @@ MI355X-first differences from the reference, none of which change results:
   use -- importing the package never touches the device (the reference creates CUDA streams at import, ``:12-13``);
 * residency policy: with ``offloading.keep_resident_if_fits`` a tensor whose offload flag is set stays in HBM while the
   running total is under ``offloading.hbm_budget_gb`` (288 GB holds HunyuanVideo's 57 GB of per-layer caches);
-* ``load_async`` records the consumer on the LOAD stream (the reference records the offload stream, ``:160``).
+* ``load_async`` records the consumer on the LOAD stream (the reference records the offload stream, ``:160``);
+* stream hand-offs are per LAYER, not per tensor: a storage's ``load_async`` gates the load stream on the compute stream once
+  for all its tensors and ``load_async_wait`` makes the compute stream wait once -- and on the offload stream only when a
+  device-to-host copy has been issued since the last wait.  Every cross-stream wait is a barrier packet that drains the compute
+  queue (~10-40 us of idle GPU each): the per-tensor form (4 gates + 8 waits per block) left 395 us of idle time at every block
+  boundary of the Wan2.1 loop (tools/step_timeline.py).
 """
 from __future__ import annotations
 
@@ -28,6 +33,7 @@ _streams: Dict[str, "torch.cuda.Stream"] = {}
 # chunks of a sequence-parallel rank) get their own slot set under the key "name#slot"
 gpu_tensors: Dict[str, List[Optional[torch.Tensor]]] = {}
 _resident_bytes = 0
+_offload_pending = False   # a device-to-host copy was issued that the compute stream has not been ordered behind yet
 
 
 def _is_dense(t: torch.Tensor) -> bool:
@@ -69,6 +75,20 @@ def offload_stream() -> "torch.cuda.Stream":
 
 def load_stream() -> "torch.cuda.Stream":
     return _side_stream("load")
+
+
+def wait_for_side_streams() -> None:
+    """Order the compute stream behind the copies issued so far: the load stream, and the offload stream if a device-to-host
+    copy is outstanding (its pinned buffer may be the next load's source)."""
+    global _offload_pending
+    if not _streams:
+        return
+    cur = torch.cuda.current_stream()
+    if "load" in _streams:
+        cur.wait_stream(_streams["load"])
+    if _offload_pending and "offload" in _streams:
+        cur.wait_stream(_streams["offload"])
+        _offload_pending = False
 
 
 class MaybeOffloadedTensor:
@@ -136,6 +156,8 @@ class MaybeOffloadedTensor:
         if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype:
             buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
             self.cpu_buf[key] = buf
+        global _offload_pending
+        _offload_pending = True
         side = offload_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -164,8 +186,13 @@ class MaybeOffloadedTensor:
             "Please call load_async() first (followed by load_async_wait())")
         return slot
 
+    def needs_host_copy(self) -> bool:
+        """True when ``load_async`` will issue a host-to-device copy (something is stored and it is not resident)."""
+        return self.real_shape[self.get_cur_model_invocation_key()] is not None and not self._is_resident_now()
+
     @torch.compiler.disable
-    def load_async(self) -> Optional[torch.Tensor]:
+    def load_async(self, gate: bool = True) -> Optional[torch.Tensor]:
+        """``gate=False``: the caller has already ordered the load stream behind the compute stream for this layer."""
         key = self.get_cur_model_invocation_key()
         shape = self.real_shape[key]
         if shape is None:  # nothing stored yet
@@ -178,17 +205,17 @@ class MaybeOffloadedTensor:
             slot = torch.empty_strided(shape, stride, dtype=self.cpu_buf[key].dtype, device=self.device)
             gpu_tensors[self.slot_name][self.layer_key] = slot
         side = load_stream()
-        side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
+        if gate:
+            side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
         with torch.cuda.stream(side):
             slot.copy_(self.cpu_buf[key][: slot.numel()].as_strided(shape, stride), non_blocking=True)
             slot.record_stream(side)
         return slot
 
+    def waits_on_side_streams(self) -> bool:
+        return self.is_offload_enabled or not self._is_resident_now()
+
     def load_async_wait(self) -> None:
-        if self._is_resident_now() and not self.is_offload_enabled:
+        if not self.waits_on_side_streams():
             return
-        if not _streams:
-            return
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(load_stream())
-        cur.wait_stream(offload_stream())
+        wait_for_side_streams()

@@ -76,6 +76,7 @@ def test_wan_and_flux_lines():
     assert w["config"]["workload"].startswith("wan_c5") and "fp8" in w["dtype"] and "csp_mlp_mm1_fp8" in w["kernels"]
     assert w["offload"]["modules_offloaded"] >= 1 and w["offload"]["pinned_host_bytes_read_per_sparse_step"] > 0
     assert w["invocation_kinds_seen"]["sparse"] > 0 and w["dense_gpu_comparator"]["sparse_over_dense"] > 0
+    assert w["resident_leg"]["value"] > 0 and w["resident_leg"]["over_the_offloaded_run"] > 0.5   # the residency policy, measured by a second process
     f = _bench("--workload", "flux_c2", "--layers", "6", "--steps", "6", "--warmup", "12", "--dense-steps", "1")
     _check_common(f, 6, 12)
     assert f["config"]["workload"].startswith("flux_c2") and {"csp_attn", "csp_mlp_mm2"} <= set(f["kernels"])

@@ -147,6 +147,8 @@ def build_wan(dev, args, timer):
             y = bench.dense_mlp(xm, blk["fc1_dense"], blk["fc2"])
         return torch.addcmul(x, m[5], y)
 
+    stall_probe = [] if os.environ.get("WAN_STALL_PROBE") == "1" else None
+
     def step(i):
         """One denoise step = n_inv model invocations (reference wan/text2video.py: cond + uncond forward per timestep)."""
         with torch.no_grad():
@@ -161,7 +163,14 @@ def build_wan(dev, args, timer):
                 for li, blk in enumerate(layers):
                     nxt = layers[(li + 1) % L]
                     if inference_step > 0 or li > 0 or inv > 0:
-                        blk["attn"].storage.load_async_wait()
+                        if stall_probe is not None:   # WAN_STALL_PROBE=1: GPU time the compute stream spends waiting for the side streams
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            blk["attn"].storage.load_async_wait()
+                            e1.record()
+                            stall_probe.append((kinds[-1], e0, e1))
+                        else:
+                            blk["attn"].storage.load_async_wait()
                     nxt["attn"].storage.load_async()
                     x = block(blk, x, inv, li, "sparse")
                 step_cache.store(x)
@@ -222,6 +231,12 @@ def build_wan(dev, args, timer):
         per_step, n_mods = offload_bytes()
         out = {"invocation_kinds_seen": {k: kinds.count(k) for k in set(kinds)},
                "offload": {"pinned_host_bytes_read_per_sparse_step": per_step, "modules_offloaded": n_mods}}
+        if stall_probe:
+            torch.cuda.synchronize()
+            by = {}
+            for kind, e0, e1 in stall_probe:
+                by.setdefault(kind, []).append(e0.elapsed_time(e1))
+            out["side_stream_wait_ms_per_block"] = {k: {"mean": round(sum(v) / len(v), 4), "max": round(max(v), 3), "n": len(v)} for k, v in by.items()}
         return out
 
     extra = {"peak_tflops": {"csp_mlp_mm1_fp8": MFMA_FP8_PEAK_TFS}, "cpu_baseline": cpu_baseline, "line": line}
