@@ -17,6 +17,8 @@ Workloads (synthetic shapes, random-init weights, inputs resident in HBM before 
 * ``hunyuan_sp`` (default at ``--gpus N > 1``; configs[3]): the same model sharded over N ranks -- attention
   head-parallel (24/N heads per rank, RCCL all-to-all over xGMI, pipelined over head chunks so the exchange hides
   behind attention), MLP sequence-parallel (118 800/N rows per rank).  Strong scaling: total work is fixed.
+  Default window = the N = 1 headline's: the whole 50-step schedule with the step cache executed (3 warm-up steps), so the per-N
+  values the driver divides by each other measure the same job.
 * ``flux_c2`` (configs[1]): FLUX.1-dev 1280x768, 57 blocks through SparseDiffAttn + SparseDiffMlp.
 
 * ``wan_c5`` (configs[4]): Wan2.1 T2V 1.3B shapes, fp8 sparse MLP + sparse attention + pinned-host caches.
@@ -62,8 +64,8 @@ MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50 hunyuan_c3 = one whole schedule, 20 hunyuan_sp, 50 flux)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 3 hunyuan_c3, 5 hunyuan_sp, 50 flux)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50 hunyuan_c3 / hunyuan_sp at N > 1 = one whole schedule, 50 flux, 10 wan)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 3 hunyuan, 50 flux, 12 wan)")
     ap.add_argument("--workload", default="auto", choices=["auto", "hunyuan_c3", "hunyuan_sp", "flux_c2", "wan_c5"])
     ap.add_argument("--launch-only", action="store_true",
                     help="start the ranks, rendezvous, all-reduce once, print one JSON line with every rank's identity and exit "
@@ -1171,16 +1173,20 @@ def main():
         args.workload = "hunyuan_c3" if world == 1 else "hunyuan_sp"
     hunyuan = args.workload.startswith("hunyuan")
     wan = args.workload == "wan_c5"
-    if hunyuan and world == 1 and args.workload == "hunyuan_c3" and not args.no_step_caching:
-        args.step_caching = True        # BASELINE.json configs[2] as worded: "93% attn sparsity + step caching"
+    auto_sp = args.workload == "hunyuan_sp" and world > 1
+    if hunyuan and (args.workload == "hunyuan_c3" and world == 1 or auto_sp) and not args.no_step_caching:
+        # BASELINE.json configs[2] as worded: "93% attn sparsity + step caching".  The N > 1 run is the SAME schedule strong-scaled (the driver
+        # divides the per-N values by each other): same 50-step window, same step cache
+        args.step_caching = True
+    whole_schedule = hunyuan and args.step_caching and (args.workload == "hunyuan_c3" or auto_sp)
     if args.steps is None:
         # hunyuan_c3: 50 steps = ONE WHOLE SCHEDULE wherever the window starts (the odometer wraps after step 49): step 0 dense, the
         # three mask-recompute steps, 21 sparse steps and the 25 steps the step cache skips -- the headline is the schedule, not a
         # window of it (a 20-step window from step 5 holds 11 of the 25 skipped steps and would flatter it)
-        args.steps = (50 if args.workload == "hunyuan_c3" and args.step_caching else 20) if hunyuan else 50 if not wan else 10
+        args.steps = (50 if whole_schedule else 20) if hunyuan else 50 if not wan else 10
     if args.warmup is None:
         # hunyuan_c3: steps 0 (dense), 1 (mask), 2 (sparse) run every kernel of the schedule once; any 50-step window is the whole schedule
-        args.warmup = (3 if args.workload == "hunyuan_c3" and args.step_caching else 5) if hunyuan else 50 if not wan else 12
+        args.warmup = (3 if whole_schedule else 5) if hunyuan else 50 if not wan else 12
     if args.dense_steps < 0:
         args.dense_steps = 1 if hunyuan else 3 if not wan else 2
 

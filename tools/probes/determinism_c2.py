@@ -17,7 +17,7 @@ out0 = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
 G = M // 128
 inds = torch.stack([torch.randperm(F, device=dev, generator=g) for _ in range(G)]).to(torch.int32)
 counts = torch.full((G,), keep, dtype=torch.int32, device=dev)
-def rep(name, fn, n=12):
+def rep(name, fn, n=int(__import__("os").environ.get("DET_N", "12"))):
     ref = fn()
     diff = sum(0 if all(torch.equal(x, y) for x, y in zip(ref, fn())) else 1 for _ in range(n - 1))
     print(f"{name:34s} launches that differ from the first: {diff} of {n - 1}")
