@@ -53,6 +53,12 @@ def test_hunyuan_line_with_its_legs():
     assert d["running_max_fallback_leg"]["csp_128_attn_avg_ms"] > 0
     assert 0.75 < d["sparsity_82_leg"]["column_sparsity"] < 0.86 and 0.90 < d["column_sparsity"] < 0.95
     assert d["roofline"]["traffic_source"] is None or d["roofline"]["traffic_source"].startswith("profiles/")
+    # a 3-step window is not the schedule: the line says what the whole 50-step schedule runs at and how far the window is from it
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.check_window_declared(d)
+    assert d["whole_schedule_steps_per_s"] > 0 and d["window_bias"] == pytest.approx(d["value"] / d["whole_schedule_steps_per_s"])
+    assert d["tracking"]["every_step_computed_steps_5_24_steps_per_s"] > 0
 
 
 def test_hunyuan_line_without_the_step_cache_has_the_step_caching_leg():

@@ -67,8 +67,9 @@ def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts):
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]),
                                           (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)])])
 def test_mm1_scatter_equals_mm1_then_scatter_add(dev, M, K, F, counts, variant):
-    """csp_mlp_mm1_scatter == csp_mlp_mm1 followed by csp_scatter_add, bit for bit, in c AND in the cache (the last
-    shape has 34 groups x 8 column tiles: it exercises the tail-split 64x64 sub-tiles as well)."""
+    """csp_mlp_mm1_scatter == csp_mlp_mm1 followed by csp_scatter_add, bit for bit, in c AND in the cache.  (The last
+    shape has 34 groups x 8 column tiles = 272 tiles on 512 resident slots: ONE tile per workgroup -- the persistent loop's later iterations and
+    the tail split are covered by tests/test_gpu_mlp_bench_shape.py at the FLUX launch shape.)"""
     from chipmunk_amd import _native
     a, b = randn_bf16(M, K, seed=1, scale=0.5), randn_bf16(F, K, seed=2, scale=0.1)
     bias, cache = randn_bf16(F, seed=3, scale=0.2), randn_bf16(F, M, seed=4, scale=0.3)
