@@ -936,8 +936,8 @@ int check_common(const void *q, const void *k, const void *v, const void *o, int
     CM_CHECK(q && k && v && o, "attention: null tensor pointer");
     CM_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: B,H,Nq,Nk must be positive (got %d,%d,%d,%d)", B, H, Nq, Nk);
     CM_CHECK((int64_t)B * H * ((Nq + QG - 1) / QG) < (1ll << 31), "attention: too many query groups");
-    CM_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0,
-             "attention: q/k/v must be 16-byte aligned and o 8-byte aligned");
+    CM_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
+             "attention: q/k/v/o must be 16-byte aligned (the epilogues store whole rows as 16-byte pieces)");
     return CHIPMUNK_OK;
 }
 int check_strides(const int64_t *s, const char *name) {
@@ -980,7 +980,7 @@ extern "C" int chipmunk_csp_attn_out(const void *q, const void *k, const void *v
                                      const int64_t o_strides[3], const int32_t *indices, const int32_t *counts, int B,
                                      int H, int Nq, int Nk, int idx_stride, int o_scale, void *stream) {
     if (int e = check_common(q, k, v, o_out, B, H, Nq, Nk)) return e;
-    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 7) == 0, "csp_attn_out: o_in missing or not 8-byte aligned");
+    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 15) == 0, "csp_attn_out: o_in missing or not 16-byte aligned");
     CM_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
     CM_CHECK(indices && counts, "csp_attn_out: indices / counts missing");
     if (int e = check_strides(q_strides, "q")) return e;
@@ -1004,7 +1004,7 @@ extern "C" int chipmunk_csp_attn_out_ragged(const void *q, const void *k, const 
                                             const int64_t o_strides[3], const int32_t *indices, const int64_t *idx_offsets,
                                             const int32_t *counts, int B, int H, int Nq, int Nk, int o_scale, void *stream) {
     if (int e = check_common(q, k, v, o_out, B, H, Nq, Nk)) return e;
-    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 7) == 0, "csp_attn_out_ragged: o_in missing or not 8-byte aligned");
+    CM_CHECK(o_in != nullptr && ((uintptr_t)o_in & 15) == 0, "csp_attn_out_ragged: o_in missing or not 16-byte aligned");
     CM_CHECK(o_scale == 1 || o_scale == -1, "o_scale must be 1 or -1");
     CM_CHECK(indices && counts && idx_offsets, "csp_attn_out_ragged: indices / offsets / counts missing");
     CM_CHECK(((uintptr_t)indices & 15) == 0, "csp_attn_out_ragged: indices must be 16-byte aligned");

@@ -21,6 +21,7 @@ def block_mean(x: torch.Tensor, mbm: int) -> torch.Tensor:
     one-pass kernel (``mlp.fused_block_mean``: fp32 sums, one rounding -- torch's reduction in another summation order)."""
     b, n, c = x.shape
     if (x.is_cuda and x.dtype == torch.bfloat16 and mbm % 4 == 0 and c % 8 == 0 and n % mbm == 0
+            and b * (n // mbm) < 65536       # the kernel's row blocks ride on grid.y
             and amd_key("mlp", "fused_block_mean")):
         return torch.ops.chipmunk.block_mean(x, mbm)
     return x.reshape(b, n // mbm, mbm, c).mean(dim=2)

@@ -11,8 +11,8 @@ MI355X-first differences from the reference, none of which change results:
   running total is under ``offloading.hbm_budget_gb`` (288 GB holds HunyuanVideo's 57 GB of per-layer caches);
 * ``load_async`` records the consumer on the LOAD stream (the reference records the offload stream, ``:160``);
 * stream hand-offs are per LAYER, not per tensor: a storage's ``load_async`` gates the load stream on the compute stream once
-  for all its tensors and ``load_async_wait`` makes the compute stream wait once -- and on the offload stream only when a
-  device-to-host copy has been issued since the last wait.  Every cross-stream wait is a barrier packet that drains the compute
+  for all its tensors and ``load_async_wait`` makes the compute stream wait once, on the load stream only: a host-to-device
+  copy that depends on a device-to-host copy waits on that copy's event on the load stream.  Every cross-stream wait is a barrier packet that drains the compute
   queue (~10-40 us of idle GPU each): the per-tensor form (4 gates + 8 waits per block) left 395 us of idle time at every block
   boundary of the Wan2.1 loop (tools/step_timeline.py).
 """
@@ -28,12 +28,15 @@ from ..config import GLOBAL_CONFIG, amd_key
 PIPELINE_DEPTH = 2
 assert PIPELINE_DEPTH > 1, "a pipeline depth of 1 would serialise every layer behind its own host copy"
 
-_streams: Dict[str, "torch.cuda.Stream"] = {}
+_streams: Dict[tuple, "torch.cuda.Stream"] = {}   # (kind, device index): one process drives one GPU, but nothing here assumes it
 # device slots shared by all layers: gpu_tensors[name][layer % PIPELINE_DEPTH]; modules that serve the SAME layer (head
 # chunks of a sequence-parallel rank) get their own slot set under the key "name#slot"
 gpu_tensors: Dict[str, List[Optional[torch.Tensor]]] = {}
 _resident_bytes = 0
-_offload_pending = False   # a device-to-host copy was issued that the compute stream has not been ordered behind yet
+# the newest device-to-host copy per device: an EVENT recorded on the offload stream behind it.  A host-to-device copy waits on it ON THE
+# LOAD STREAM (its pinned source, or the device slot it refills, may be what that copy is still reading) -- whichever compute stream,
+# and however many of them, consume the loaded value: they only ever wait on the load stream.
+_last_offload_event: Dict[int, "torch.cuda.Event"] = {}
 
 
 def _is_dense(t: torch.Tensor) -> bool:
@@ -64,9 +67,10 @@ def release_resident(nbytes: int) -> None:
 
 
 def _side_stream(kind: str) -> "torch.cuda.Stream":
-    if kind not in _streams:
-        _streams[kind] = torch.cuda.Stream()
-    return _streams[kind]
+    key = (kind, torch.cuda.current_device())
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream()
+    return _streams[key]
 
 
 def offload_stream() -> "torch.cuda.Stream":
@@ -78,17 +82,12 @@ def load_stream() -> "torch.cuda.Stream":
 
 
 def wait_for_side_streams() -> None:
-    """Order the compute stream behind the copies issued so far: the load stream, and the offload stream if a device-to-host
-    copy is outstanding (its pinned buffer may be the next load's source)."""
-    global _offload_pending
-    if not _streams:
-        return
-    cur = torch.cuda.current_stream()
-    if "load" in _streams:
-        cur.wait_stream(_streams["load"])
-    if _offload_pending and "offload" in _streams:
-        cur.wait_stream(_streams["offload"])
-        _offload_pending = False
+    """Order the CURRENT compute stream behind the host-to-device copies issued so far.  (The offload stream is not waited on here: a load
+    that depends on a device-to-host copy waits on that copy's event on the load stream, see ``load_async`` -- so any number of compute
+    streams stay correct, and none of them drains its queue for a copy it does not consume.)"""
+    key = ("load", torch.cuda.current_device())
+    if key in _streams:
+        torch.cuda.current_stream().wait_stream(_streams[key])
 
 
 class MaybeOffloadedTensor:
@@ -156,14 +155,16 @@ class MaybeOffloadedTensor:
         if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype:
             buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
             self.cpu_buf[key] = buf
-        global _offload_pending
-        _offload_pending = True
         side = offload_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             # same strides on both sides: one hipMemcpyAsync of the storage, whatever the dimension order
             buf[: gpu_tensor.numel()].as_strided(gpu_tensor.shape, self.real_stride[key]).copy_(gpu_tensor, non_blocking=True)
             gpu_tensor.record_stream(side)
+        ev = _last_offload_event.get(gpu_tensor.device.index)
+        if ev is None:
+            ev = _last_offload_event[gpu_tensor.device.index] = torch.cuda.Event()
+        ev.record(side)
 
     def offload_cur_value(self) -> None:
         self.offload(self.get_loaded_value())
@@ -207,6 +208,9 @@ class MaybeOffloadedTensor:
         side = load_stream()
         if gate:
             side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
+            ev = _last_offload_event.get(slot.device.index)
+            if ev is not None:
+                side.wait_event(ev)   # the pinned source was written, and the slot last read, by a device-to-host copy no newer than this
         with torch.cuda.stream(side):
             slot.copy_(self.cpu_buf[key][: slot.numel()].as_strided(shape, stride), non_blocking=True)
             slot.record_stream(side)

@@ -122,3 +122,28 @@ def test_chunk_modules_of_one_layer_have_their_own_load_slots(cfg):
             assert got[c].shape == data[l][c].shape and torch.equal(got[c], data[l][c]), (l, c)
         assert len({g.data_ptr() for g in got}) == n_chunks
     assert set(ot.gpu_tensors) == {"attn.out_cache", "attn.out_cache#1", "attn.out_cache#2"}
+
+
+def test_two_compute_streams_each_see_their_loaded_values(cfg):
+    """The offload -> load dependency is an event the LOAD stream waits on, not a process-wide flag one compute stream clears: two
+    compute streams that each offload, update and reload their own tensors (large enough for the copies to be in flight when the
+    other stream asks) both read back what they stored."""
+    from chipmunk_amd.util.storage import MaybeOffloadedTensor
+    cfg["offloading"]["global_disable_offloading"] = False
+    cfg["offloading"]["mlp.out_cache"] = True
+    cfg["offloading"]["attn.out_cache"] = True
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    names = ["mlp.out_cache", "attn.out_cache"]
+    holders = [MaybeOffloadedTensor(n, 0, torch.bfloat16, dev) for n in names]
+    base = [torch.randn(64 << 20, device=dev).to(torch.bfloat16) for _ in names]      # 128 MiB each
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for s, h, b in zip(streams, holders, base):
+            with torch.cuda.stream(s):
+                h.offload(b + rnd)               # device-to-host on the offload stream, behind stream s
+        for s, h, b in zip(reversed(streams), reversed(holders), reversed(base)):
+            with torch.cuda.stream(s):
+                h.load_async(); h.load_async_wait()
+                got = h.get_loaded_value()
+                assert torch.equal(got, b + rnd), f"round {rnd}: {h.name} read back stale data on its own compute stream"
