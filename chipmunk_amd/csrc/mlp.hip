@@ -489,6 +489,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void mm1_kernel(const Mm1Params p) {
     }
 }
 
+#include "mlp_pc.h"
+
 // ------------------------------------------------------------------------------------------------ mm2
 struct Mm2Params {
     const uint16_t *a, *b;  // a = packed [M,F], b = fc2^T [F,N2]
@@ -903,6 +905,12 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
         case 8: return launch_mm1_variant<128, 64, 2, 3>(p, stream, cache_updated);
         case 9: return launch_mm1_variant<128, 64, 2, 4>(p, stream, cache_updated);
         case 10: return launch_mm1_variant<256, 64, 3, 1, false, 8>(p, stream, cache_updated);
+        case 20:   // producer / consumer form (mlp_pc.h); needs two k steps
+            if (K >= 128) {
+                if (cache_updated) *cache_updated = update_cache != 0;
+                return launch_mm1pc<false>(p, stream);
+            }
+            [[fallthrough]];
         default: return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*)
     }
 }
@@ -961,5 +969,6 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
                    indices, counts, M, K, F, 0, 0, 0, 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
     if (chipmunk_get_option("mm1_variant") == 10) return launch_mm1_variant<256, 64, 3, 1, true, 8>(p, (hipStream_t)stream);
+    if (chipmunk_get_option("mm1_variant") == 20 && K >= 256) return launch_mm1pc<true>(p, (hipStream_t)stream);
     return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }

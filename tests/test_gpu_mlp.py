@@ -47,8 +47,12 @@ def test_mm1_known_answer_reversed_identity(dev):
     assert_close_bf16(c, ref.flip(1), what="mm1 vs torch formula")
 
 
+@pytest.mark.parametrize("variant", [0, 20])
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768])])
-def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts):
+def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts, variant, request):
+    from chipmunk_amd import _native
+    _native.set_option("mm1_variant", variant)
+    request.addfinalizer(lambda: _native.set_option("mm1_variant", 0))
     a, b = randn_bf16(M, K, seed=1, scale=0.5), randn_bf16(F, K, seed=2, scale=0.1)
     bias, cache = randn_bf16(F, seed=3, scale=0.2), randn_bf16(F, M, seed=4, scale=0.3)
     cnt = torch.tensor(counts, dtype=torch.int32)
@@ -63,7 +67,7 @@ def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts):
         assert (c[g * 128:(g + 1) * 128, n:].float() == sentinel).all()
 
 
-@pytest.mark.parametrize("variant", [0, 4, 10])  # 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles
+@pytest.mark.parametrize("variant", [0, 4, 10, 20])  # 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]),
                                           (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)])])
 def test_mm1_scatter_equals_mm1_then_scatter_add(dev, M, K, F, counts, variant):
@@ -157,7 +161,7 @@ def test_run_e2e_matches_dense_delta(dev):
     assert_close_bf16(out_cache, ref, atol=6e-2, rtol=3e-2, what="sparse step output")
 
 
-@pytest.mark.parametrize("variant", [0, 10])   # 10: 8 waves on 128 x 256 tiles
+@pytest.mark.parametrize("variant", [0, 10, 20])   # 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
 @pytest.mark.parametrize("update_cache", [False, True])
 def test_mm1_fp8_vs_oracle(dev, update_cache, variant, request):
     """BASELINE config C5: fp8 e4m3fn GEMM1 (reference triton/csp_mlp_mm1.py:37-164), Wan-like K = 1536."""
@@ -226,7 +230,7 @@ def test_sparse_mlp_module_fp8_path(dev, fresh_config):
 
 
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 128, 768, [0, 768, 256]), (512, 1536, 1024, [512, 256, 1024, 768])])
-@pytest.mark.parametrize("variant", [0, 10])
+@pytest.mark.parametrize("variant", [0, 10, 20])
 def test_fp8_mm1_scatter_equals_fp8_mm1_then_scatter_add(dev, M, K, F, counts, variant, request):
     """csp_mlp_mm1_fp8_scatter == csp_mlp_mm1_fp8 (update_cache off) followed by csp_scatter_add: bit for bit in the packed deltas
     AND in the activation cache (the fp8 counterpart of the bf16 fusion test above)."""

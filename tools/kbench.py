@@ -266,7 +266,7 @@ def main():
     variants = [int(x) for x in args.variants.split(",")]
     for w in args.what:
         if w in ("mm1", "mm1s", "mm2", "scatter"):
-            bench_mlp(w, variants)
+            bench_mlp(w, variants, keep=int(os.environ.get("KB_KEEP", "4096")))   # KB_KEEP: kept columns per group (FLUX: 0.3 * 12288 -> 3840)
         elif w == "fp8_wan":
             bench_fp8_wan()
         elif w == "mm2_wan":          # GEMM2 at the Wan2.1 1.3B shape (configs[4]): M = 32 768 rows, N2 = 1 536, F = 8 960, 30 % kept

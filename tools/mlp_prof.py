@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--wan", action="store_true", help="the Wan2.1 shape (M 32768, K 1536, F 8960, keep 2688); mm1 only: fp8 with --fp8")
     ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--pc", action="store_true", help="timeline of the producer / consumer GEMM1 (mm1_variant 20): one workgroup, tiles 0 and 1")
+    ap.add_argument("--keep", type=int, default=0)
     args = ap.parse_args()
     if args.build_only or not os.path.exists(LIB):
         build()
@@ -40,7 +42,9 @@ def main():
         assert lib.chipmunk_set_option(name.encode(), int(val)) == 0
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    M, K, F, keep = 4352, 3072, 12288, 4096
+    M, K, F, keep = 4352, 3072, 12288, args.keep or 4096
+    if args.pc:
+        assert lib.chipmunk_set_option(b"mm1_variant", 20) == 0
     if args.wan:
         M, K, F, keep = 32768, 1536, 8960, 2688
         args.layers = min(args.layers, 2)
@@ -88,6 +92,18 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print(f"{args.what}: {e0.elapsed_time(e1) * 100:.1f} us per launch (instrumented build)")
+    if args.pc:
+        pb = (ctypes.c_uint64 * 64)()
+        assert lib.chipmunk_pc_prof_read(pb) == 0
+        t0 = pb[15]
+        cn = ["tile start", "before B(0)", "B(0) passed", "k loop done (E0 passed)", "epilogue arithmetic done", "E1 passed", "E2 passed", "stores issued"]
+        pn = ["tile start", "offsets ready", "2 stages issued", "k loop done", "cache block landed", "E0 passed", "E1 passed", "E2 passed", "stores issued"]
+        for t in range(2):
+            for role, names_ in ((0, cn), (1, pn)):
+                vals = [pb[t * 32 + role * 16 + i] for i in range(len(names_))]
+                print(f"  tile {t} {'consumer' if role == 0 else 'producer'} (ticks since kernel entry; delta): " +
+                      "; ".join(f"{nm} {v - t0} (+{v - (vals[i - 1] if i else t0)})" for i, (nm, v) in enumerate(zip(names_, vals)) if v))
+        return
     buf = (ctypes.c_uint64 * 128)()
     assert lib.chipmunk_mlp_prof_read(buf) == 0
     names = ["vmcnt wait", "barrier", "dma issue", "frags+mfma", "loop exit", "epilogue"]
