@@ -202,3 +202,75 @@ def test_bench_launcher_starts_n_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-only"], env=env2,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "--gpus 4" in (bad.stderr + bad.stdout)
+
+
+def _worker8(rank, world, port, ret):
+    """BASELINE configs[3] at its REAL proportions, scaled down: 8 ranks, 24 heads (3 per rank, uneven chunks [1, 2] -- what plan_chunks picks at
+    N = 8), image rows divisible by 8 plus text rows, query groups dealt 78 x 7 + 75 -> here 13 x 7 + 11 two-row groups with a ragged last
+    one.  Both pipelines against the unsharded attention; bytes per layer against DESIGN.md section 7's formulas."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from chipmunk_amd import distributed as D
+    D.setup_dist(dist.group.WORLD, rank, world)
+    try:
+        b, a, d, s_txt = 1, 24, 8, 5
+        ls = 25                                  # image rows per rank (118 800 / 8 = 14 850 in the real run)
+        s_img = ls * world
+        lh = a // world
+        g = torch.Generator().manual_seed(11)
+        img_full = torch.randn(3, b, s_img, a, d, generator=g)
+        txt_full = torch.randn(3, b, s_txt, a, d, generator=g)
+        qf, kf, vf = [torch.cat([img_full[i], txt_full[i]], dim=1).permute(0, 2, 1, 3) for i in range(3)]   # [b, a, n, d]
+        ref = F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3)                               # [b, n, a, d]
+        n_tok = s_img + s_txt
+        esz = 4
+        # ---- heads: the reference's all-to-all exchange, pipelined in uneven head chunks
+        assert lh == 3
+        pipe = D.HeadParallelPipeline(dist.group.WORLD, a, ls, s_txt, d, torch.float32, torch.device("cpu"), chunks=[1, 2])
+        shapes = []
+
+        def attn_h(q, k, v):
+            shapes.append(tuple(q.shape))
+            return F.scaled_dot_product_attention(q, k, v)
+        for rep in range(2):                     # buffers are reused across layers
+            o_img, o_txt = pipe.run(img_full[:, :, rank * ls:(rank + 1) * ls].contiguous(), txt_full, [attn_h, attn_h])
+            torch.testing.assert_close(o_img, ref[:, rank * ls:(rank + 1) * ls].reshape(b, ls, a * d), rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(o_txt, ref[:, s_img:].reshape(b, s_txt, a * d), rtol=1e-5, atol=1e-5)
+        assert shapes[:2] == [(b, 1, n_tok, d), (b, 2, n_tok, d)], shapes
+        # DESIGN.md section 7: (N - 1) * (s_img / N) * (h / N) * 4 * d * esz bytes leave the GPU per layer (q, k, v in + o out)
+        assert pipe.bytes_per_layer_sent == (world - 1) * ls * lh * b * 4 * d * esz
+        # ---- groups: whole query groups per rank for all heads, K / V all-gathered per head chunk; 103 two-row groups -> 13 x 7 + 12 (the last ragged)
+        rows = D.group_rows(n_tok, world, group=2)
+        assert rows == [26] * 7 + [23] and sum(rows) == n_tok
+        assert D.group_rows(119056, 8) == [14976] * 7 + [14224]          # the real split: 78 x 7 + 75 groups of 192 rows
+        lo = sum(rows[:rank])
+        gp = D.GroupParallelPipeline(dist.group.WORLD, a, rows, d, torch.float32, torch.device("cpu"), chunks=[6, 18])
+        seen = []
+
+        def attn_g(q, k, v):
+            seen.append((q.shape[1], q.shape[2], k.shape[2]))
+            return F.scaled_dot_product_attention(q, k, v)
+        for rep in range(2):
+            og = gp.run(qf[:, :, lo:lo + rows[rank]].contiguous(), kf[:, :, lo:lo + rows[rank]].contiguous(),
+                        vf[:, :, lo:lo + rows[rank]].contiguous(), [attn_g, attn_g])
+            torch.testing.assert_close(og, ref[:, lo:lo + rows[rank]].reshape(b, rows[rank], a * d), rtol=1e-5, atol=1e-5)
+        assert seen[:2] == [(6, rows[rank], n_tok), (18, rows[rank], n_tok)], seen
+        # DESIGN.md section 7: 2 * (N - 1) * rows_max * h * d * esz bytes arrive per layer (K and V of the other ranks' rows, padded to the longest share)
+        assert gp.bytes_per_layer_received == (world - 1) * 2 * b * a * max(rows) * d * esz
+        # the two shardings' traffic: groups moves N / 2 times what heads moves (1.28 vs 0.32 GB per layer at the real size)
+        real_heads = 7 * (118800 // 8) * 3 * 4 * 128 * 2
+        real_groups = 7 * 2 * 24 * 14976 * 128 * 2
+        assert abs(real_heads / 1e9 - 0.319) < 0.002 and abs(real_groups / 1e9 - 1.288) < 0.002
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_shape_world8():
+    """Eight gloo ranks on this host (no GPU): the C4 split at its real head / chunk / group proportions through both pipelines."""
+    world, port = 8, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}
