@@ -14,7 +14,7 @@ SYMBOLS = [
     "chipmunk_csp_attn", "chipmunk_csp_attn_out", "chipmunk_csp_128_attn", "chipmunk_dense_attn", "chipmunk_dense_colsum_attn",
     "chipmunk_csp_mlp_mm1", "chipmunk_csp_mlp_mm1_scatter", "chipmunk_csp_mlp_mm1_fp8", "chipmunk_csp_mlp_mm2_and_scatter_add", "chipmunk_csp_scatter_add", "chipmunk_csp_mlp_mm2",
     "chipmunk_topk_indices", "chipmunk_topk_delta_indices", "chipmunk_topk_mask", "chipmunk_mask_to_indices", "chipmunk_mask_to_sorted_indices", "chipmunk_packed_mask_to_indices", "chipmunk_copy_indices",
-    "chipmunk_bitpack", "chipmunk_bitunpack", "chipmunk_transpose16", "chipmunk_block_mean", "chipmunk_gather_rows", "chipmunk_qkv_split_norm", "chipmunk_dense_colsum_topk_mask", "chipmunk_dense_attn_strided", "chipmunk_csp_attn_out_ragged", "chipmunk_compact_indices", "chipmunk_residual_ln_modulate", "chipmunk_dense_colsum_attn_strided", "chipmunk_dense_colsum_topk_mask_strided", "chipmunk_release_scratch", "chipmunk_big_scratch_fallbacks",
+    "chipmunk_bitpack", "chipmunk_bitunpack", "chipmunk_transpose16", "chipmunk_block_mean", "chipmunk_quantize_fp8", "chipmunk_gather_rows", "chipmunk_qkv_split_norm", "chipmunk_dense_colsum_topk_mask", "chipmunk_dense_attn_strided", "chipmunk_csp_attn_out_ragged", "chipmunk_compact_indices", "chipmunk_residual_ln_modulate", "chipmunk_dense_colsum_attn_strided", "chipmunk_dense_colsum_topk_mask_strided", "chipmunk_release_scratch", "chipmunk_big_scratch_fallbacks",
 ]
 
 _lib = None

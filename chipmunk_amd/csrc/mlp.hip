@@ -244,8 +244,8 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
     // bf16: the bias seeds the fp32 accumulators, as in the reference (csp_mlp_mm1.cu:347-350) -- its two dependent loads (index,
     // then bias) fly during the prologue instead of in front of the epilogue.  fp8 scales the sum first, so it starts from zero.
     constexpr bool SEED_BIAS = !FP8;
-    float bias_v[NT4], sab = 1.f;   // loaded here for both forms: in front of the epilogue the two round trips would be exposed
-    if constexpr (FP8) sab = p.scale_a[0] * p.scale_b[0];
+    float bias_v[NT4], sa = 1.f, sb = 1.f;   // loaded here for both forms: in front of the epilogue the round trips would be exposed
+    if constexpr (FP8) sa = p.scale_a[0], sb = p.scale_b[0];
     f32x16 acc[MT][NT4];
 #pragma unroll
     for (int n4 = 0; n4 < NT4; ++n4) {
@@ -359,43 +359,62 @@ __device__ __forceinline__ void mm1_tile(const Mm1Params &p, unsigned char *smem
         // The output stage is plain row-major: a ds_write_b16 puts 32 consecutive columns of one row (64 contiguous bytes) per half
         // wave, and the 16-byte read-back below walks whole rows, so neither side needs a swizzle (the cache block does: its 32 lanes
         // of a read hit 32 rows of the [column][m] image at one m).  Two values per instruction wherever the ISA has a packed form.
+        // The arithmetic is specialised on update_cache (three straight-line copies: with a branch per element group hipcc serialises the groups,
+        // one exposed LDS round trip each) and reads the cache values of a whole 32-column tile ahead of that tile's arithmetic.
+        auto arith = [&](auto upd_) {
+            constexpr int UPD = decltype(upd_)::value;
+            u32x2 cv[2][MT][4];
+            auto cptr = [&](int n4, int mt, int q4) {
+                const int jl = wn * (TN / WNC) + n4 * 32 + (lane & 31), ml = wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                return Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2;
+            };
+            auto load = [&](int n4) {
 #pragma unroll
-        for (int n4 = 0; n4 < NT4; ++n4) {
-            const int jl = wn * (TN / WNC) + n4 * 32 + (lane & 31);
-            const float bia = bias_v[n4];
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                    for (int q4 = 0; q4 < 4; ++q4) cv[n4 & 1][mt][q4] = *(const u32x2 *)cptr(n4, mt, q4);
+            };
+            load(0);
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int ml = wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
-                    unsigned char *cp = Ct + jl * (TM * 2) + (((ml >> 3) ^ (jl & (LPR - 1))) << 4) + (ml & 7) * 2;
-                    const u32x2 cv = *(const u32x2 *)cp;
-                    const f32x2 c01 = {__uint_as_float(cv[0] << 16), __uint_as_float(cv[0] & 0xffff0000u)};
-                    const f32x2 c23 = {__uint_as_float(cv[1] << 16), __uint_as_float(cv[1] & 0xffff0000u)};
-                    f32x2 a01 = {acc[mt][n4][q4 * 4 + 0], acc[mt][n4][q4 * 4 + 1]}, a23 = {acc[mt][n4][q4 * 4 + 2], acc[mt][n4][q4 * 4 + 3]};
-                    uint32_t d01, d23, n01 = 0, n23 = 0;   // packed deltas as stored (bf16 pairs); the cache block's new values
-                    if constexpr (FP8) {
-                        // acc*scale_a*scale_b + bias -> gelu -> bf16, then a bf16 subtract (csp_mlp_mm1.py:121-133)
-                        const f32x2 sv = {sab, sab}, bv = {bia, bia};
-                        const uint32_t t01 = pack_bf16x2_v(gelu_tanh2(__builtin_elementwise_fma(a01, sv, bv)));
-                        const uint32_t t23 = pack_bf16x2_v(gelu_tanh2(__builtin_elementwise_fma(a23, sv, bv)));
-                        d01 = pack_bf16x2_v(unpack_bf16x2(t01) - c01), d23 = pack_bf16x2_v(unpack_bf16x2(t23) - c23);
-                        if (p.update_cache == 2) n01 = t01, n23 = t23;   // 2: cache = new activation, what the reference's Triton kernel does (csp_mlp_mm1.py:140)
-                    } else {
-                        // the bias is already in the sum (SEED_BIAS)
-                        d01 = pack_bf16x2_v(gelu_tanh2(a01) - c01), d23 = pack_bf16x2_v(gelu_tanh2(a23) - c23);
-                    }
-                    uint16_t *op = (uint16_t *)(ot_row(ml) + jl * 2);   // (rows ml .. ml+3: on one side of the split, a multiple of 4)
-                    op[0] = (uint16_t)d01, op[TN] = (uint16_t)(d01 >> 16), op[2 * TN] = (uint16_t)d23, op[3 * TN] = (uint16_t)(d23 >> 16);
-                    if (p.update_cache) {
-                        // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
-                        if (!(FP8 && p.update_cache == 2))
-                            n01 = pack_bf16x2_v(c01 + unpack_bf16x2(d01)), n23 = pack_bf16x2_v(c23 + unpack_bf16x2(d23));
-                        *(u32x2 *)cp = (u32x2){n01, n23};
+            for (int n4 = 0; n4 < NT4; ++n4) {
+                if (n4 + 1 < NT4) load(n4 + 1);
+                const int jl = wn * (TN / WNC) + n4 * 32 + (lane & 31);
+                const float bia = bias_v[n4];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int ml = wm * (TM / 2) + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                        const u32x2 c = cv[n4 & 1][mt][q4];
+                        const f32x2 c01 = unpack_bf16x2(c[0]), c23 = unpack_bf16x2(c[1]);
+                        f32x2 a01 = {acc[mt][n4][q4 * 4 + 0], acc[mt][n4][q4 * 4 + 1]}, a23 = {acc[mt][n4][q4 * 4 + 2], acc[mt][n4][q4 * 4 + 3]};
+                        uint32_t d01, d23, n01 = 0, n23 = 0;   // packed deltas as stored (bf16 pairs); the cache block's new values
+                        if constexpr (FP8) {
+                            // (acc * scale_a) * scale_b + bias in the reference's order -> gelu -> bf16, then a bf16 subtract (csp_mlp_mm1.py:121-133)
+                            const f32x2 sav = {sa, sa}, sbv = {sb, sb}, bv = {bia, bia};
+                            const uint32_t t01 = pack_bf16x2_v(gelu_tanh2((a01 * sav) * sbv + bv));
+                            const uint32_t t23 = pack_bf16x2_v(gelu_tanh2((a23 * sav) * sbv + bv));
+                            d01 = pack_bf16x2_v(unpack_bf16x2(t01) - c01), d23 = pack_bf16x2_v(unpack_bf16x2(t23) - c23);
+                            if constexpr (UPD == 2) n01 = t01, n23 = t23;   // 2: cache = new activation, what the reference's Triton kernel does (csp_mlp_mm1.py:140)
+                        } else {
+                            // the bias is already in the sum (SEED_BIAS)
+                            d01 = pack_bf16x2_v(gelu_tanh2(a01) - c01), d23 = pack_bf16x2_v(gelu_tanh2(a23) - c23);
+                        }
+                        uint16_t *op = (uint16_t *)(ot_row(ml) + jl * 2);   // (rows ml .. ml+3: on one side of the split, a multiple of 4)
+                        op[0] = (uint16_t)d01, op[TN] = (uint16_t)(d01 >> 16), op[2 * TN] = (uint16_t)d23, op[3 * TN] = (uint16_t)(d23 >> 16);
+                        if constexpr (UPD != 0) {
+                            // 1: cache += delta in bf16, exactly what csp_scatter_add does (scatter_add.cu:43-98)
+                            if constexpr (!(FP8 && UPD == 2))
+                                n01 = pack_bf16x2_v(c01 + unpack_bf16x2(d01)), n23 = pack_bf16x2_v(c23 + unpack_bf16x2(d23));
+                            *(u32x2 *)cptr(n4, mt, q4) = (u32x2){n01, n23};
+                        }
                     }
                 }
             }
-        }
+        };
+        if (p.update_cache == 0) arith(ic<0>{});
+        else if (p.update_cache == 1) arith(ic<1>{});
+        else arith(ic<2>{});
         __syncthreads();
         constexpr int O_INST = EPI / (1024 * NW);  // 1 KiB row-major pieces per wave
 #pragma unroll
@@ -490,6 +509,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mm1_kernel(const Mm1Params p) {
 }
 
 #include "mlp_pc.h"
+#include "mlp_pp.h"
 
 // ------------------------------------------------------------------------------------------------ mm2
 struct Mm2Params {
@@ -911,6 +931,12 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
                 return launch_mm1pc<false>(p, stream);
             }
             [[fallthrough]];
+        case 21:   // producer / consumer form with the DMA stream running across tile boundaries (mlp_pp.h); needs six k steps
+            if (K >= 384 && chipmunk_get_option("mm1_variant") == 21) {
+                if (cache_updated) *cache_updated = update_cache != 0;
+                return launch_mm1pp<false>(p, stream);
+            }
+            [[fallthrough]];
         default: return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*)
     }
 }
@@ -967,8 +993,9 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
              "csp_mlp_mm1_fp8: operand too large for 32-bit offsets");
     // same tile machinery as the bf16 kernel (buffer-form DMA, tail split, staged epilogue); a k step is 128 fp8 values
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
-                   indices, counts, M, K, F, 0, 0, 0, 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
+                   indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
     if (chipmunk_get_option("mm1_variant") == 10) return launch_mm1_variant<256, 64, 3, 1, true, 8>(p, (hipStream_t)stream);
     if (chipmunk_get_option("mm1_variant") == 20 && K >= 256) return launch_mm1pc<true>(p, (hipStream_t)stream);
+    if (chipmunk_get_option("mm1_variant") == 21 && K >= 768) return launch_mm1pp<true>(p, (hipStream_t)stream);
     return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }

@@ -1,0 +1,391 @@
+// GEMM1, producer / consumer form with the DMA stream running ACROSS tile boundaries (included by mlp.hip after mlp_pc.h; same operands
+// and epilogue arithmetic as mm1_kernel: reference csrc/mlp/csp_mlp_mm1.cu:207-390, src/chipmunk/triton/csp_mlp_mm1.py:37-164).
+//
+// What the measurements of mlp_pc.h (mm1_variant 20) said: with the roles split, a consumer wave runs its k step in ~1.15 x the MFMA time
+// and the four producer waves move a stage every ~0.9 us (gathered rows that miss L2) -- the k loop is bound by the DMA stream, and
+// everything that stops that stream at a tile boundary (next tile's index loads, the first stages' latency, the epilogue, the stores:
+// ~8 us per tile) is pure loss; with Wan2.1's 12-k-step fp8 tiles it is most of the tile.  A 128 x 256 tile cannot keep the stream
+// running through its epilogue: cache block + output stage are 128 KiB of the 160.  A 128 x 128 tile can:
+//   LDS  [0, 96 Ki)     ring of three 32 KiB operand stages (global stage G of the workgroup's tile sequence lives in slot G % 3)
+//        [96, 128 Ki)   cache block of the tile whose epilogue comes next (32 KiB, [column][m], chunk-swizzled)
+//        [128, 160 Ki)  output stage (row-major); during the k loop its first 512 bytes carry the NEXT tile's gather indices from the
+//                       consumers (plain loads) to the producers, whose vector-memory stream therefore holds nothing but DMA pieces
+//   producers (waves 4-7): after barrier B(kb) of tile j issue global stage kb + 2 -- the next TILE's stages 0 and 1 after the last two
+//        k steps, so two stages are in flight while the consumers are in the epilogue -- and the tile's cache block after B(0);
+//   consumers (waves 0-3, 64 x 64 each): k loop as in mlp_pc.h, epilogue straight behind it, stores drain under the next k loop.
+// Barriers per tile: B(0) .. B(nkb-1), E0 (cache block landed, k loop done), E1 (deltas staged).  No barrier separates tiles: a consumer
+// arrives at the next B(0) with its LDS reads of this tile's stages done, which is all the producers' next cache-block DMA needs.
+constexpr int PP_TN = 128, PP_STAGE = 32768, PP_A = 16384, PP_CT = 3 * PP_STAGE, PP_OT = PP_CT + 32768, PP_LDS = PP_OT + 32768;
+static_assert(PP_LDS == 163840, "the whole LDS of a CU");
+
+struct PpTile {
+    int g, n0, cnt, slot;
+    bool valid;
+};
+// next live tile of this workgroup at or after `slot` (tiles past counts[g] are skipped, csp_mlp_mm1.cu:233-243); every wave walks the same list
+__device__ __forceinline__ PpTile pp_next(const Mm1Params &p, const PcTileWalk &tw, int slot) {
+    PpTile t;
+    t.valid = false, t.g = 0, t.n0 = 0, t.cnt = 0;
+    for (; slot < tw.pl.mine; slot += tw.stride) {
+        const TileMap tm = tile_at(tw.pl, slot);
+        const int cnt = p.counts[tm.g];
+        if (tm.nt * PP_TN < cnt) {
+            t.valid = true, t.g = tm.g, t.n0 = tm.nt * PP_TN, t.cnt = cnt;
+            break;
+        }
+    }
+    t.slot = slot;
+    return t;
+}
+
+template <bool FP8>
+__device__ __forceinline__ void pp_producer(const Mm1Params &p, unsigned char *smem, const PcTileWalk &tw, int w, int lane) {
+    using KT = KTile<64>;
+    constexpr uint32_t ESZ = FP8 ? 1u : 2u;
+    const int pw = w & 3, nkb = tw.nkb;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a), rb = make_rsrc(p.b), rc = make_rsrc(p.cache);
+    const int32_t *idxbuf = (const int32_t *)(smem + PP_OT);
+    PpTile cur = pp_next(p, tw, blockIdx.x >> 3);
+    if (!cur.valid) {   // (cannot happen for a launched workgroup unless every tile of its list is dead; the consumers return likewise)
+        return;
+    }
+    uint32_t aoff[4], boff[4], coff[8], naoff[4], nboff[4], ncoff[8];
+    auto a_offsets = [&](const PpTile &t, uint32_t (&ao)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = KT::lane_row(pw * 4 + i, lane);
+            ao[i] = (uint32_t)(t.g * BM + row) * p.K * ESZ + KT::src_chunk_elems(row, lane) * 2u;
+        }
+    };
+    {   // first tile: its gather indices straight from memory (nothing is in flight yet)
+        const int32_t *idxg = p.indices + (int64_t)cur.g * p.F;
+        a_offsets(cur, aoff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = KT::lane_row(pw * 4 + i, lane);
+            const int j = cur.n0 + row;
+            boff[i] = (uint32_t)idxg[j < cur.cnt ? j : cur.n0] * p.K * ESZ + KT::src_chunk_elems(row, lane) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int jj = (pw * 8 + i) * 4 + (lane >> 4);
+            const int j = cur.n0 + jj;
+            coff[i] = ((uint32_t)idxg[j < cur.cnt ? j : cur.n0] * p.M + cur.g * BM + (((lane & 15) ^ (jj & 15)) << 3)) * 2u;
+        }
+    }
+    int G = 0;   // global stage counter: the slot of the next stage to issue
+    auto issue = [&](const uint32_t (&ao)[4], const uint32_t (&bo)[4], int kb) {
+        unsigned char *st = smem + (G % 3) * PP_STAGE;
+        ++G;
+        const bool hot = p.probe & 1;     // (timing probe 1: every piece re-reads one hot line -- the DMA stream without its memory traffic)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) blds16(ra, hot ? 0u : ao[i], hot ? 0 : kb * 128, st + (pw * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) blds16(rb, hot ? 0u : bo[i], hot ? 0 : kb * 128, st + PP_A + (pw * 4 + i) * 1024);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the index loads above: from here on this wave's vector-memory stream is DMA pieces only
+    issue(aoff, boff, 0);
+    issue(aoff, boff, 1);
+    for (;;) {
+        const PpTile nxt = pp_next(p, tw, cur.slot + tw.stride);
+        a_offsets(nxt.valid ? nxt : cur, naoff);
+        for (int kb = 0; kb < nkb; ++kb) {
+            // stage kb has landed.  Younger pieces that may fly on: the next stage (8); around the cache block (issued after B(0), behind
+            // stage 2) that block as well (8 more)
+            if (kb == 1 || kb == 2) wait_vmcnt<16>();
+            else wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();       // B(kb)
+            if (kb == 4) {
+                // the consumers put the next tile's 128 gather indices into the index buffer before arriving at B(4)
+                if (nxt.valid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = KT::lane_row(pw * 4 + i, lane);
+                        nboff[i] = (uint32_t)idxbuf[row] * p.K * ESZ + KT::src_chunk_elems(row, lane) * 2u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int jj = (pw * 8 + i) * 4 + (lane >> 4);
+                        ncoff[i] = ((uint32_t)idxbuf[jj] * p.M + nxt.g * BM + (((lane & 15) ^ (jj & 15)) << 3)) * 2u;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nboff[i] = boff[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ncoff[i] = coff[i];
+                }
+            }
+            if (kb + 2 < nkb) issue(aoff, boff, kb + 2);
+            else issue(naoff, nboff, kb + 2 - nkb);   // the next tile's first stages (after the last tile: two stages nobody reads); nkb >= 6
+            if (kb == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) blds16(rc, coff[i], 0, smem + PP_CT + (pw * 8 + i) * 1024);
+            }
+        }
+        // (the cache block is older than stage 3, which has landed)
+        __builtin_amdgcn_s_barrier();           // E0
+        __builtin_amdgcn_s_barrier();           // E1
+        if (!nxt.valid) break;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] = naoff[i], boff[i] = nboff[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) coff[i] = ncoff[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two stages issued past the last tile must land before the workgroup's LDS goes away
+}
+
+template <bool FP8>
+__device__ __forceinline__ void pp_consumer(const Mm1Params &p, unsigned char *smem, const PcTileWalk &tw, int w, int lane) {
+    const int l31 = lane & 31, wm = w >> 1, wn = w & 1, nkb = tw.nkb;   // 2 x 2 waves of 64 x 64
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned char *Ct = smem + PP_CT, *Ot = smem + PP_OT;
+    int32_t *idxbuf = (int32_t *)(smem + PP_OT);
+    const uint32_t sw = (uint32_t)(l31 >> 1) & 7u;
+    const uint32_t abase = lds0 + (uint32_t)l31 * 128u + (uint32_t)wm * 8192u;
+    const uint32_t bbase = lds0 + (uint32_t)l31 * 128u + (uint32_t)(PP_A + wn * 8192);
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    constexpr int KK = FP8 ? 2 : 4, RPF = FP8 ? 2 : 1, RD = 4 * RPF;
+    float sa = 1.f, sb = 1.f;
+    if constexpr (FP8) sa = p.scale_a[0], sb = p.scale_b[0];
+    PpTile cur = pp_next(p, tw, blockIdx.x >> 3);
+    if (!cur.valid) return;
+    float bias_v[2], bias_n[2] = {0.f, 0.f};
+    {
+        const int32_t *idxg = p.indices + (int64_t)cur.g * p.F;
+#pragma unroll
+        for (int n4 = 0; n4 < 2; ++n4) {
+            const int j = cur.n0 + wn * 64 + n4 * 32 + l31;
+            bias_v[n4] = bf16_bits_to_f32(p.bias[idxg[j < cur.cnt ? j : cur.n0]]);
+        }
+    }
+    int G = 0;   // global stage counter: the slot of the next stage to read
+    for (;;) {
+        const PpTile nxt = pp_next(p, tw, cur.slot + tw.stride);
+        const int32_t *idxg = p.indices + (int64_t)cur.g * p.F;
+        const int32_t *idxn = p.indices + (int64_t)nxt.g * p.F;
+        // cache columns of this wave's 8 cache-block pieces (write-back): plain loads issued here, first used after the k loop
+        int32_t ccol[8];
+        if (p.update_cache) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = cur.n0 + (w * 8 + i) * 4 + (lane >> 4);
+                ccol[i] = idxg[j < cur.cnt ? j : cur.n0];
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int n4 = 0; n4 < 2; ++n4) {
+            const float seed = FP8 ? 0.f : bias_v[n4];   // bf16: the bias seeds the sums (csp_mlp_mm1.cu:347-350); fp8 scales the sum first
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][n4][r] = seed;
+        }
+        u32x4 fa[2][2][RPF], fb[2][2][RPF];
+        auto read1 = [&](int gstage, int kk, int set, int r) {
+            const int q = r / 4, f = r % 4;
+            const uint32_t st = (uint32_t)(gstage % 3) * PP_STAGE;
+            const uint32_t c = FP8 ? (uint32_t)(kk * 4 + (lane >> 5) * 2 + q) : (uint32_t)(kk * 2 + (lane >> 5));
+            const uint32_t co = st + ((c ^ sw) << 4);
+            if (f < 2) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(fa[set][f][q]) : "v"(abase + co), "i"(f * 4096) : "memory");
+            else asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(fb[set][f - 2][q]) : "v"(bbase + co), "i"((f - 2) * 4096) : "memory");
+        };
+        auto mfma1 = [&](int set, int i) {
+            const int n4 = i >> 1, mt = i & 1;
+            if constexpr (FP8) {
+                const u32x4 a0 = fa[set][mt][0], a1 = fa[set][mt][1], b0 = fb[set][n4][0], b1 = fb[set][n4][1];
+                const i32x8 av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                const i32x8 bv = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+                acc[mt][n4] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[mt][n4], 0, 0, 0, 0, 0, 0);
+            } else {
+                acc[mt][n4] = mfma32(__builtin_bit_cast(bf16x8, fa[set][mt][0]), __builtin_bit_cast(bf16x8, fb[set][n4][0]), acc[mt][n4]);
+            }
+        };
+        // one k slice: 4 MFMAs on fragment set `set`, the next slice's reads (if any) in the gaps behind them
+        auto slice = [&](int set, bool has_next, int ngstage, int nkk) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int q = 0; q < RPF; ++q) asm volatile("" : "+v"(fa[set][f][q]), "+v"(fb[set][f][q]));
+            static_for<0, 4>([&](auto ic_) {
+                constexpr int i = decltype(ic_)::value;
+                mfma1(set, i);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) {
+#pragma unroll
+                    for (int r = i * RPF; r < (i + 1) * RPF; ++r) read1(ngstage, nkk, set ^ 1, r);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        __builtin_amdgcn_s_barrier();           // B(0)
+#pragma unroll
+        for (int r = 0; r < RD; ++r) read1(G, 0, 0, r);
+        int32_t idx_next = 0;
+        for (int kb = 0; kb < nkb; ++kb) {
+            // the next tile's gather indices travel to the producers through the index buffer (the output stage's first 512 bytes, idle during
+            // the k loop): loaded behind B(0), stored behind B(3), so that they are visible to everybody behind B(4); its bias values likewise
+            if (kb == 0 && nxt.valid && w < 2) {
+                const int j = nxt.n0 + w * 64 + lane;
+                idx_next = idxn[j < nxt.cnt ? j : nxt.n0];
+            }
+            if (kb == 3 && nxt.valid && w < 2) idxbuf[w * 64 + lane] = idx_next;
+            if (kb == 4 && nxt.valid) {
+#pragma unroll
+                for (int n4 = 0; n4 < 2; ++n4) bias_n[n4] = bf16_bits_to_f32(p.bias[idxbuf[wn * 64 + n4 * 32 + l31]]);
+            }
+            if (p.probe & 2) {                  // (timing probe 2: no fragment reads, no MFMAs)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                ++G;
+                continue;
+            }
+            static_for<0, KK>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                constexpr int set = kk & 1;     // KK is even: the sets alternate seamlessly across k steps
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (kk + 1 < KK) {
+                    slice(set, true, G, kk + 1);
+                } else {
+                    // every read of this stage has returned: hand the slot back (B(kb+1), or E0 after the last k step) BEFORE the slice's MFMAs
+                    __builtin_amdgcn_s_barrier();
+                    slice(set, kb + 1 < nkb, G + 1, 0);
+                }
+            });
+            ++G;
+        }
+        // ---- epilogue (E0 passed): lane owns packed column jl = lane&31 of each 32 x 32 tile and rows (r&3) + 8*(r>>2) + 4*(lane>>5):
+        //      C[m, j] = bf16(gelu(acc + bias[idx]) - cache[idx, m])     (csp_mlp_mm1.cu:354-390; fp8: csp_mlp_mm1.py:121-133)
+        // The arithmetic is specialised on update_cache (three straight-line copies: a branch per element group keeps hipcc from overlapping the
+        // groups) and reads the cache values of a whole 32-column tile ahead of its arithmetic (one LDS round trip per tile, not per group).
+        auto arith = [&](auto upd_) {
+            constexpr int UPD = decltype(upd_)::value;
+            u32x2 cv[2][2][4];
+            auto cptr = [&](int n4, int mt, int q4) {
+                const int jl = wn * 64 + n4 * 32 + l31, ml = wm * 64 + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                return Ct + jl * 256 + (((ml >> 3) ^ (jl & 15)) << 4) + (ml & 7) * 2;
+            };
+            auto load = [&](int n4) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cv[n4 & 1][mt][q4] = *(const u32x2 *)cptr(n4, mt, q4);
+            };
+            load(0);
+#pragma unroll
+            for (int n4 = 0; n4 < 2; ++n4) {
+                if (n4 + 1 < 2) load(n4 + 1);
+                const int jl = wn * 64 + n4 * 32 + l31;
+                const float bia = bias_v[n4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int ml = wm * 64 + mt * 32 + q4 * 8 + (lane >> 5) * 4;
+                        const u32x2 c = cv[n4 & 1][mt][q4];
+                        const f32x2 c01 = unpack_bf16x2(c[0]), c23 = unpack_bf16x2(c[1]);
+                        f32x2 a01 = {acc[mt][n4][q4 * 4 + 0], acc[mt][n4][q4 * 4 + 1]}, a23 = {acc[mt][n4][q4 * 4 + 2], acc[mt][n4][q4 * 4 + 3]};
+                        uint32_t d01, d23, n01 = 0, n23 = 0;
+                        if constexpr (FP8) {
+                            // (acc * scale_a) * scale_b + bias in the reference's order -> gelu -> bf16, then a bf16 subtract
+                            const f32x2 sav = {sa, sa}, sbv = {sb, sb}, bv = {bia, bia};
+                            const uint32_t t01 = pack_bf16x2_v(gelu_tanh2((a01 * sav) * sbv + bv));
+                            const uint32_t t23 = pack_bf16x2_v(gelu_tanh2((a23 * sav) * sbv + bv));
+                            d01 = pack_bf16x2_v(unpack_bf16x2(t01) - c01), d23 = pack_bf16x2_v(unpack_bf16x2(t23) - c23);
+                            if constexpr (UPD == 2) n01 = t01, n23 = t23;   // the cache takes the new activation (csp_mlp_mm1.py:140)
+                        } else {
+                            d01 = pack_bf16x2_v(gelu_tanh2(a01) - c01), d23 = pack_bf16x2_v(gelu_tanh2(a23) - c23);
+                        }
+                        uint16_t *op = (uint16_t *)(Ot + ml * (PP_TN * 2) + jl * 2);
+                        op[0] = (uint16_t)d01, op[PP_TN] = (uint16_t)(d01 >> 16), op[2 * PP_TN] = (uint16_t)d23, op[3 * PP_TN] = (uint16_t)(d23 >> 16);
+                        if constexpr (UPD != 0) {
+                            if constexpr (!(FP8 && UPD == 2))   // cache += delta in bf16, what csp_scatter_add does (scatter_add.cu:43-98)
+                                n01 = pack_bf16x2_v(c01 + unpack_bf16x2(d01)), n23 = pack_bf16x2_v(c23 + unpack_bf16x2(d23));
+                            *(u32x2 *)cptr(n4, mt, q4) = (u32x2){n01, n23};
+                        }
+                    }
+                }
+            }
+        };
+        if (p.probe & 4) {                      // (timing probe 4: no epilogue arithmetic)
+            float t = 0.f;
+#pragma unroll
+            for (int n4 = 0; n4 < 2; ++n4)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[mt][n4][r];
+            if (t == 123.456f) Ot[lane] = 1;
+        } else if (p.update_cache == 0) arith(ic<0>{});
+        else if (p.update_cache == 1) arith(ic<1>{});
+        else arith(ic<2>{});
+        __syncthreads();                        // E1: the deltas (and the updated cache block) of all four consumer waves are staged
+        // outputs: 32 row-major 1 KiB pieces (four 256-byte rows each), 8 per consumer wave; the updated cache block the way it came
+        u32x4 ov[8], cvv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = *(const u32x4 *)(Ot + (w * 8 + i) * 1024 + lane * 16);
+        if (p.update_cache) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cvv[i] = *(const u32x4 *)(Ct + (w * 8 + i) * 1024 + lane * 16);
+        }
+        if (!(p.probe & 8))                     // (timing probe 8: no output stores)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (w * 8 + i) * 4 + (lane >> 4), ch = lane & 15;
+            const int j = cur.n0 + ch * 8;
+            uint16_t *cp = p.c + (int64_t)(cur.g * BM + r) * p.F + j;
+            if (j + 8 <= cur.cnt && (p.F & 7) == 0) {
+                *(u32x4 *)cp = ov[i];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (j + e < cur.cnt) cp[e] = (uint16_t)(ov[i][e >> 1] >> ((e & 1) * 16));
+            }
+        }
+        if (p.update_cache) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int jj = (w * 8 + i) * 4 + (lane >> 4);
+                const uint32_t coff = ((uint32_t)ccol[i] * p.M + cur.g * BM + (((lane & 15) ^ (jj & 15)) << 3)) * 2u;
+                if (cur.n0 + jj < cur.cnt) *(u32x4 *)((unsigned char *)p.cache + coff) = cvv[i];
+            }
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        bias_v[0] = bias_n[0], bias_v[1] = bias_n[1];
+        // (the LDS reads above have returned -- their data went into the stores -- before this wave reaches the next tile's B(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool FP8>
+__global__ __launch_bounds__(512, 1) void mm1pp_kernel(const Mm1Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PcTileWalk tw;
+    tw.pl = plan_tiles<PP_TN>(p.counts, p.M / BM, p.NT, p.NR, 0, 1);
+    tw.stride = (int)(gridDim.x >> 3);
+    tw.nkb = (int)((uint32_t)p.K * (FP8 ? 1u : 2u) / 128u);
+    tw.first = 0;
+    if (w >= 4) pp_producer<FP8>(p, smem, tw, w, lane);
+    else pp_consumer<FP8>(p, smem, tw, w, lane);
+}
+
+template <bool FP8>
+int launch_mm1pp(const Mm1Params &p0, hipStream_t s) {
+    auto kern = mm1pp_kernel<FP8>;
+    static uint64_t lds_set = 0;
+    ensure_dynamic_lds((const void *)kern, PP_LDS, lds_set);
+    Mm1Params p = p0;
+    p.NT = (p.F + PP_TN - 1) / PP_TN;
+    p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
+    if (p.NR > p.NT) p.NR = p.NT;
+    const int per_xcd_max = device_cu_count() / 8;          // one workgroup per CU
+    const int tiles_per_xcd = ((p.M / BM) * p.NT + 7) / 8;
+    const int per_xcd = tiles_per_xcd < per_xcd_max ? tiles_per_xcd : per_xcd_max;
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(512), PP_LDS, s, p);
+    CM_LAUNCH_CHECK();
+    return CHIPMUNK_OK;
+}

@@ -536,6 +536,19 @@ at::Tensor block_mean(at::Tensor x, int64_t mbm) {
     return out;
 }
 
+// F8Linear.quantize_input as one kernel: (x * scale).clamp(-max, max).to(float8_e4m3fn), same roundings
+at::Tensor quantize_fp8(at::Tensor x, at::Tensor scale, double max_value) {
+    CHECK_DEV(x); CHECK_DEV(scale);
+    TORCH_CHECK(x.scalar_type() == at::kBFloat16, "quantize_fp8: x must be bfloat16");
+    TORCH_CHECK(scale.scalar_type() == at::kFloat && scale.numel() == 1, "quantize_fp8: scale must be a one-element float32 tensor");
+    TORCH_CHECK(x.numel() % 8 == 0, "quantize_fp8: the element count must be a multiple of 8");
+    x = x.contiguous();
+    c10::DeviceGuard guard(x.device());
+    at::Tensor out = at::empty(x.sizes(), x.options().dtype(at::kFloat8_e4m3fn));
+    check(chipmunk_quantize_fp8(x.data_ptr(), scale.data_ptr<float>(), out.data_ptr(), x.numel(), (float)max_value, cur_stream(x)), "quantize_fp8");
+    return out;
+}
+
 // ascending-order variant of (packed_)mask_to_indices (same set / counts / padding; see chipmunk_hip.h)
 std::vector<at::Tensor> mask_to_sorted_indices(at::Tensor mask, at::IntArrayRef shape, int64_t multiple_of,
                                                int64_t pad_to_multiple_of) {
@@ -760,6 +773,7 @@ TORCH_LIBRARY(chipmunk, m) {
     m.def("residual_ln_modulate(Tensor x, Tensor? y, Tensor? gate, Tensor shift, Tensor scale, float eps) -> Tensor[]");
     m.def("transpose_last2(Tensor x) -> Tensor");
     m.def("block_mean(Tensor x, int mbm) -> Tensor");
+    m.def("quantize_fp8(Tensor x, Tensor scale, float max_value) -> Tensor");
     m.def("bitpack(Tensor mask) -> Tensor");
     m.def("bitunpack(Tensor packed, int[] shape) -> Tensor");
     m.def("gather_rows(Tensor src, Tensor map) -> Tensor");
@@ -795,6 +809,7 @@ TORCH_LIBRARY_IMPL(chipmunk, CUDA, m) {
     m.impl("topk_mask", &topk_mask);
     m.impl("transpose_last2", &transpose_last2);
     m.impl("block_mean", &block_mean);
+    m.impl("quantize_fp8", &quantize_fp8);
     m.impl("bitpack", &bitpack);
     m.impl("bitunpack", &bitunpack);
     m.impl("gather_rows", &gather_rows);

@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 from torch.nn import init
 
+from ..util.config import amd_key
+
 
 def amax_to_scale(amax: torch.Tensor, max_val: float) -> torch.Tensor:
     return (max_val / torch.clamp(amax, min=1e-12)).clamp(max=max_val)
@@ -123,6 +125,10 @@ class F8Linear(nn.Module):
                 self.input_scale_initialized = True
             self.input_scale = amax_to_scale(amax, self.input_max_value)
             self.input_scale_reciprocal = self.input_scale.reciprocal()
+        if (x.is_cuda and x.dtype == torch.bfloat16 and self.input_float8_dtype == torch.float8_e4m3fn and x.numel() % 8 == 0
+                and self.input_scale.dtype == torch.float32 and amd_key("mlp", "fused_fp8_quantize")):
+            # the three elementwise kernels below as one pass, bit-identical (tests/test_gpu_mlp.py::test_quantize_fp8_matches_the_torch_chain)
+            return torch.ops.chipmunk.quantize_fp8(x, self.input_scale.reshape(1), float(self.input_max_value))
         return to_fp8_saturated(x, self.input_scale, self.input_max_value).to(self.input_float8_dtype)
 
     def reset_parameters(self) -> None:

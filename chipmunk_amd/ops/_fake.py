@@ -71,6 +71,10 @@ def _register():
     def _(x, mbm):
         return x.new_empty((x.shape[0], x.shape[1] // mbm, x.shape[2]))
 
+    @lib.register_fake("chipmunk::quantize_fp8")
+    def _(x, scale, max_value):
+        return x.new_empty(x.shape, dtype=torch.float8_e4m3fn)
+
     @lib.register_fake("chipmunk::bitpack")
     def _(mask):
         return mask.new_empty(((mask.numel() + 7) // 8,), dtype=torch.uint8)

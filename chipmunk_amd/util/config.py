@@ -85,6 +85,8 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     "mlp.fused_topk_delta": True,
     # block means of the MLP input (first op of every sparse MLP step) as one HBM-rate kernel instead of torch's reshape + mean
     "mlp.fused_block_mean": True,
+    # F8Linear.quantize_input ((x * scale).clamp().to(fp8): three elementwise kernels in torch) as one kernel, same bits
+    "mlp.fused_fp8_quantize": True,
     # sparse attention step as ONE kernel (cache + delta -> new tensor) instead of clone + in-place accumulate
     "attn.fused_residual": True,
     # mask-building step: randint + topk + scatter_ + mask combines of `random_and_topk` as one kernel

@@ -249,6 +249,11 @@ int chipmunk_transpose16(const void *src, void *dst, int B, int R, int C, void *
  * mbm % 4 == 0, C % 8 == 0. */
 int chipmunk_block_mean(const void *x, void *out, int64_t rows, int C, int mbm, void *stream);
 
+/* bf16 [n] -> OCP fp8 e4m3 [n]: F8Linear.quantize_input's `(x * scale).clamp(-max, max).to(float8_e4m3fn)` (reference
+ * src/chipmunk/modules/mlp_fp8.py, the input side of csp_mlp_mm1_fp8) as one pass with the same roundings (fp32 product -> bf16 -> clamp ->
+ * e4m3, round-to-nearest-even).  scale: one float on the device.  n % 8 == 0. */
+int chipmunk_quantize_fp8(const void *x, const float *scale, void *out, int64_t n, float max_value, void *stream);
+
 /* bitpack / bitunpack (reference src/chipmunk/ops/bitpack.py:4-69): 8 bools -> 1 byte, little-endian, flat. */
 int chipmunk_bitpack(const void *mask, void *packed, int64_t n, void *stream);
 int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);

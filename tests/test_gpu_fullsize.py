@@ -431,3 +431,26 @@ def test_plan_tail_cut_items_match_uncut_and_oracle():
             o_ref = oracle.csp_128_attn(q[:, H - 1:, r0:r1].contiguous(), k[:, H - 1:], v[:, H - 1:], inds[:, H - 1:, gi:gi + 1].contiguous(),
                                         counts[:, H - 1:, gi:gi + 1].contiguous())
             assert_close_bf16(o_cut[:, H - 1:, r0:r1], o_ref, what=f"cut item (head {H - 1}, group {gi}) vs oracle, attn_csp96={opt}")
+
+
+def test_c5_wan_cross_attention_shape(dev):
+    """Wan2.1's cross-attention over the 512 text tokens as the Wan workload calls it (tools/wan_workload.py): q = head views of a
+    [32 768, 12 * 128] projection output, k / v = head views of one [512, 2, 12, 128] projection output, output token-major.
+    chipmunk.dense_attn_layout vs fp32 SDPA on row slices, and the token-major view in front of the output projection is free."""
+    H, M, T, D = 12, 32768, 512, 128
+    g = torch.Generator(device=dev).manual_seed(71)
+    xq = torch.randn(M, H * D, device=dev, dtype=torch.bfloat16, generator=g)
+    xkv = torch.randn(1, T, 2, H, D, device=dev, dtype=torch.bfloat16, generator=g)
+    q = xq.view(1, M, H, D).transpose(1, 2)
+    k, v = xkv[:, :, 0].transpose(1, 2), xkv[:, :, 1].transpose(1, 2)
+    assert not q.is_contiguous() and not k.is_contiguous()
+    o, l = torch.ops.chipmunk.dense_attn_layout(q, k, v, True)
+    assert o.shape == (1, H, M, D) and l.shape == (1, H, M, 1)
+    flat = o.transpose(1, 2).reshape(M, H * D)
+    assert flat.data_ptr() == o.data_ptr(), "token-major output: the head merge is a view"
+    for rows in (slice(0, 256), slice(17000, 17300), slice(M - 192, M)):
+        ref = torch.nn.functional.scaled_dot_product_attention(q[:, :, rows].float(), k.float(), v.float())
+        assert_close_bf16(o[:, :, rows], ref, atol=1e-2, rtol=2e-2, what="Wan cross-attention vs SDPA")
+    # the head-major form gives the same values
+    o2, _ = torch.ops.chipmunk.dense_attn(q, k, v)
+    assert torch.equal(o2, o)

@@ -47,8 +47,8 @@ def test_mm1_known_answer_reversed_identity(dev):
     assert_close_bf16(c, ref.flip(1), what="mm1 vs torch formula")
 
 
-@pytest.mark.parametrize("variant", [0, 20])
-@pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768])])
+@pytest.mark.parametrize("variant", [0, 20, 21])
+@pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]), (640, 512, 1024, [0, 1024, 136, 512, 8])])
 def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts, variant, request):
     from chipmunk_amd import _native
     _native.set_option("mm1_variant", variant)
@@ -67,9 +67,10 @@ def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts, variant, req
         assert (c[g * 128:(g + 1) * 128, n:].float() == sentinel).all()
 
 
-@pytest.mark.parametrize("variant", [0, 4, 10, 20])  # 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
+@pytest.mark.parametrize("variant", [0, 4, 10, 20, 21])  # 21: producer / consumer form, DMA stream across tiles; 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]),
-                                          (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)])])
+                                          (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)]),
+                                          (1280, 448, 2048, [2048 - 24 * (g % 7) for g in range(10)])])
 def test_mm1_scatter_equals_mm1_then_scatter_add(dev, M, K, F, counts, variant):
     """csp_mlp_mm1_scatter == csp_mlp_mm1 followed by csp_scatter_add, bit for bit, in c AND in the cache.  (The last
     shape has 34 groups x 8 column tiles = 272 tiles on 512 resident slots: ONE tile per workgroup -- the persistent loop's later iterations and
@@ -161,7 +162,7 @@ def test_run_e2e_matches_dense_delta(dev):
     assert_close_bf16(out_cache, ref, atol=6e-2, rtol=3e-2, what="sparse step output")
 
 
-@pytest.mark.parametrize("variant", [0, 10, 20])   # 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
+@pytest.mark.parametrize("variant", [0, 10, 20, 21])   # 10: 8 waves on 128 x 256 tiles, 20 / 21: producer / consumer forms
 @pytest.mark.parametrize("update_cache", [False, True])
 def test_mm1_fp8_vs_oracle(dev, update_cache, variant, request):
     """BASELINE config C5: fp8 e4m3fn GEMM1 (reference triton/csp_mlp_mm1.py:37-164), Wan-like K = 1536."""
@@ -230,7 +231,7 @@ def test_sparse_mlp_module_fp8_path(dev, fresh_config):
 
 
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 128, 768, [0, 768, 256]), (512, 1536, 1024, [512, 256, 1024, 768])])
-@pytest.mark.parametrize("variant", [0, 10, 20])
+@pytest.mark.parametrize("variant", [0, 10, 20, 21])
 def test_fp8_mm1_scatter_equals_fp8_mm1_then_scatter_add(dev, M, K, F, counts, variant, request):
     """csp_mlp_mm1_fp8_scatter == csp_mlp_mm1_fp8 (update_cache off) followed by csp_scatter_add: bit for bit in the packed deltas
     AND in the activation cache (the fp8 counterpart of the bf16 fusion test above)."""
@@ -256,3 +257,34 @@ def test_fp8_mm1_scatter_equals_fp8_mm1_then_scatter_add(dev, M, K, F, counts, v
     assert torch.equal(c_a, c_b), "packed deltas"
     assert torch.equal(cache_a, cache_b), "activation cache"
     assert not torch.equal(cache_b, cache0) or sum(counts) == 0
+
+
+def test_quantize_fp8_matches_the_torch_chain(dev):
+    """chipmunk.quantize_fp8 == F8Linear.quantize_input's (x * scale).clamp(-448, 448).to(float8_e4m3fn), bit for bit: normal values, values
+    that saturate, ties between fp8 neighbours, the fp8 subnormal range, zeros and a NaN."""
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(4096, 1536, device=dev, generator=g)
+    x[0, :64] = torch.linspace(-3e-3, 3e-3, 64, device=dev)            # fp8 subnormals after scaling by ~40
+    x[1, :64] = torch.linspace(-20, 20, 64, device=dev)                 # saturates
+    x[2, :8] = torch.tensor([0.0, -0.0, 1.0, 1.0625, 1.1875, 0.40625, float("nan"), 448.0], device=dev)
+    x = x.to(torch.bfloat16)
+    for scale in (torch.tensor([40.7], device=dev), torch.tensor([1.0], device=dev), torch.tensor([448.0 / 5.3], device=dev)):
+        want = (x * scale[0]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+        got = torch.ops.chipmunk.quantize_fp8(x, scale, 448.0)
+        assert got.dtype == torch.float8_e4m3fn and got.shape == x.shape
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (
+            f"scale {scale.item()}: {(got.view(torch.uint8) != want.view(torch.uint8)).sum().item()} bytes differ")
+    # through the module: the fused path and the elementwise path give the same fp8 tensor
+    from chipmunk_amd.modules.mlp_fp8 import F8Linear
+    from chipmunk_amd.util import config as cfg
+    lin = F8Linear.from_linear(torch.nn.Linear(1536, 64, device=dev, dtype=torch.bfloat16), input_float8_dtype=torch.float8_e4m3fn)
+    xin = x[3:].contiguous()
+    a = lin.quantize_input(xin)
+    lin.trial_index, lin.input_scale_initialized = 0, False
+    lin.input_amax_trials.zero_()
+    cfg.GLOBAL_CONFIG["mlp"]["fused_fp8_quantize"] = False
+    try:
+        b = lin.quantize_input(xin)
+    finally:
+        cfg.GLOBAL_CONFIG["mlp"].pop("fused_fp8_quantize", None)
+    assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))

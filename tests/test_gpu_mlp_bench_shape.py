@@ -137,8 +137,12 @@ def test_plan_mirror_matches_kernel_and_split_is_taken(dev):
     assert torch.equal(untouched, expect), "the kernel's sub-tile map differs from the host mirror"
 
 
-@pytest.mark.parametrize("top", [4096, F])   # 4096: the bench's plan (2 iterations + split tail); F: one group keeps every column (96 live
-def test_mm1_bench_shape_vs_torch_and_oracle(dev, top):  # column tiles, 408 tiles per XCD = 7 persistent iterations, no split)
+@pytest.mark.parametrize("variant", [0, 20, 21])   # 20 / 21: the producer / consumer forms (own tile walks: 128 x 256 tiles, 128 x 128 with the DMA
+@pytest.mark.parametrize("top", [4096, F])   # stream across tiles).  4096: the bench's plan (2 iterations + split tail); F: one group keeps every column
+def test_mm1_bench_shape_vs_torch_and_oracle(dev, top, variant, request):  # (96 live column tiles, 408 tiles per XCD = 7 persistent iterations, no split)
+    from chipmunk_amd import _native
+    _native.set_option("mm1_variant", variant)
+    request.addfinalizer(lambda: _native.set_option("mm1_variant", 0))
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     K = 3072
     counts = bench_like_counts(4096)
@@ -190,7 +194,15 @@ def test_mm1_bench_shape_vs_torch_and_oracle(dev, top):  # column tiles, 408 til
         assert_close_bf16(c[rows], c_ref, what=f"mm1 group {g} (covers {key}) vs oracle")
 
 
-def test_mm1_fp8_split_plan_vs_torch(dev):
+@pytest.mark.parametrize("variant", [0, 20, 21])
+def test_mm1_fp8_split_plan_vs_torch(dev, variant, request):
+    from chipmunk_amd import _native
+    _native.set_option("mm1_variant", variant)
+    request.addfinalizer(lambda: _native.set_option("mm1_variant", 0))
+    _fp8_split_plan_vs_torch(dev)
+
+
+def _fp8_split_plan_vs_torch(dev):
     """The fp8 template on a launch whose plan takes the split (same 34 x 32 live tiles; Wan2.1's K and F): every group vs fp32 torch on
     the dequantised operands, as tests/test_gpu_fullsize.py::test_c5_wan_fp8_gemm1_full_size does for the (split-free) Wan launch."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count

@@ -4,7 +4,7 @@ sparse MLP with fp8 GEMM1 (SparseDiffMlp over an F8Linear fc1: chipmunk.csp_mlp_
 denoise step = TWO model invocations (cond / uncond), each with its own sparse state, through StepCache.
 
 A block = LayerNorm + modulate, QKV projection, qkv_split_norm, self-attention, output projection + gated residual,
-cross-attention over 512 text tokens (q / kv / output projections + flash SDPA), LayerNorm + modulate, the MLP, gated residual
+cross-attention over 512 text tokens (q / kv / output projections + chipmunk.dense_attn; flash SDPA in the library comparator), LayerNorm + modulate, the MLP, gated residual
 (reference examples/wan/wan/modules/model.py:265-330 block, :580-630 transformer loop).  Self-attention consumes synthetic q, k,
 v resident in HBM (three rotating sets per invocation); the MLP input drifts slowly from step to step (10 variants) so that
 the |block-mean delta| top-k has something to select, as in the FLUX workload.
@@ -78,6 +78,12 @@ def build_wan(dev, args, timer):
     mlp_ops.mm2_fused = timer.wrap("csp_mlp_mm2_and_scatter_add", mlp_ops.mm2_fused, bench._mm2_work)
     mlp_ops.csp_mlp_mm2 = timer.wrap("csp_mlp_mm2", mlp_ops.csp_mlp_mm2, bench._mm2_only_work)
 
+    def cross_work(q, k, v):
+        def work():   # QK^T + PV over the text keys; q + o once, k + v once
+            return 4.0 * q.shape[1] * q.shape[2] * k.shape[2] * D, 2.0 * (2 * q.shape[1] * q.shape[2] * D + 2 * k.shape[1] * k.shape[2] * D)
+        return work
+    cross_attn = timer.wrap("cross_attn(dense_attn)", lambda q, k, v: torch.ops.chipmunk.dense_attn_layout(q, k, v, True)[0], cross_work)
+
     def drift(i):
         return 0.15 * math.sin(0.7 * i + 0.3) + 0.02 * i
 
@@ -107,6 +113,7 @@ def build_wan(dev, args, timer):
 
     fused_rowwise = bench.HunyuanBlock.fused_rowwise
     ones = torch.ones(HID, **bf)
+    a_pad = torch.zeros(M, HID, **bf)
 
     def ln_mod(x, shift, scale):
         if fused_rowwise:                                    # LayerNorm + modulate in one pass (chipmunk.residual_ln_modulate)
@@ -128,12 +135,19 @@ def build_wan(dev, args, timer):
             o = bench.flash_sdpa(q, k, v)
         else:
             o = ops_pkg.dense_attn(q, k, v)[0]
-        a = torch.nn.functional.pad(tokens_first(o), (0, 0, 0, M - N))
+        a = a_pad                              # [M, HID] with a zero tail: the N attended rows copied in (F.pad would fill all of it first)
+        a[:N].copy_(tokens_first(o))
         x = torch.addcmul(x, m[2], torch.addmm(blk["o"].bias, a, blk["o"].weight.t()))
-        # cross-attention over the text tokens (dense, 512 keys)
+        # cross-attention over the text tokens (dense, 512 keys).  q, k, v are the strided head views of the projections' outputs.  The library
+        # comparator (how == "sdpa") keeps torch's flash SDPA here too; the other two loops call chipmunk.dense_attn on the views, with the
+        # output token-major so that the `b h s d -> s (h d)` in front of the output projection is a view (AOTriton's kernel runs this
+        # 32 768 x 512 shape at 59 TFLOP/s: 1.75 ms per call, 27 % of the round-4 Wan line's kernel time)
         cq = torch.addmm(blk["cq"].bias, x, blk["cq"].weight.t()).view(1, M, H, D).transpose(1, 2)
         ckv = torch.addmm(blk["ckv"].bias, ctx[inv], blk["ckv"].weight.t()).view(1, TXT, 2, H, D)
-        co = torch.nn.functional.scaled_dot_product_attention(cq, ckv[:, :, 0].transpose(1, 2), ckv[:, :, 1].transpose(1, 2))
+        if how == "sdpa" or os.environ.get("WAN_CROSS_SDPA") == "1":
+            co = torch.nn.functional.scaled_dot_product_attention(cq, ckv[:, :, 0].transpose(1, 2), ckv[:, :, 1].transpose(1, 2))
+        else:
+            co = cross_attn(cq, ckv[:, :, 0].transpose(1, 2), ckv[:, :, 1].transpose(1, 2))
         y = torch.addmm(blk["co"].bias, co.transpose(1, 2).reshape(M, HID), blk["co"].weight.t())
         if fused_rowwise:                                    # x + y (gate 1: the product is exact) and the LayerNorm + modulate behind it
             x, xm = ops_pkg.residual_ln_modulate(x, y, ones, m[3], m[4], 1e-6)
