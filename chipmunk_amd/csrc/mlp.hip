@@ -734,6 +734,17 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
         }
         __syncthreads();
         constexpr int ITEMS = BM * CPRO / (NW * 64);  // 16-byte pieces per thread
+        // all of the thread's C pieces are requested before the first is used: written as load -> add -> store per piece, every load
+        // sits behind the previous piece's store (same array, may alias) and hipcc drains both with vmcnt(0) -- eight serial HBM round
+        // trips at the end of every tile, and the tiles of a launch all end together
+        u32x4 olds[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = it * (NW * 64) + tid;
+            const int r = item / CPRO, ch = item % CPRO;
+            const int n = n0 + ch * 8;
+            olds[it] = n < p.N2 ? *(const u32x4 *)(p.c + (int64_t)(g * BM + r) * p.N2 + n) : (u32x4){0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const int item = it * (NW * 64) + tid;
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
             if (n >= p.N2) continue;  // N2 is a multiple of 8: a chunk is live or dead as a whole
             const u32x4 a = *(const u32x4 *)(smem + r * (BN * 2) + ((ch ^ (r & (CPRO - 1) & 31)) << 4));
             uint16_t *cp = p.c + (int64_t)(g * BM + r) * p.N2 + n;
-            const u32x4 old = *(const u32x4 *)cp;
+            const u32x4 old = olds[it];
             u32x4 out;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -802,22 +813,34 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const uint16_t *packed
         }
     }
     __syncthreads();
-    // accumulate: 64 columns x 16 chunks of 8 rows
+    // accumulate: 64 columns x 16 chunks of 8 rows (the four cache pieces of a thread are requested before the first is used: a load behind the
+    // previous piece's store would wait for both)
+    u32x4 olds[4];
+    const uint16_t *src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int item = i * 256 + tid;
         const int c = item >> 4, ch = item & 15;
+        src[i] = nullptr;
+        olds[i] = (u32x4){0u, 0u, 0u, 0u};
         if (c0 + c >= cnt) continue;
         const int col = indices[(int64_t)g * F + c0 + c];
-        uint16_t *dst = unpacked + (int64_t)col * M + g * 128 + ch * 8;
-        const u32x4 old = *(const u32x4 *)dst;
+        src[i] = unpacked + (int64_t)col * M + g * 128 + ch * 8;
+        olds[i] = *(const u32x4 *)src[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int item = i * 256 + tid;
+        const int c = item >> 4, ch = item & 15;
+        if (src[i] == nullptr) continue;
+        const u32x4 old = olds[i];
         const u32x4 add = *(const u32x4 *)(tile + c * SC_LD + ch * 8);
         u32x4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             out[e] = pack_bf16x2(__uint_as_float(old[e] << 16) + __uint_as_float(add[e] << 16),
                                  __uint_as_float(old[e] & 0xffff0000u) + __uint_as_float(add[e] & 0xffff0000u));
-        *(u32x4 *)dst = out;
+        *(u32x4 *)const_cast<uint16_t *>(src[i]) = out;
     }
 }
 
