@@ -1453,7 +1453,7 @@ def main():
             cpu_baseline_hunyuan(n_layers, wl.N, projections=not args.no_projections) if hunyuan else
             wan_extra["cpu_baseline"]() if wan else cpu_baseline_flux(n_layers)),
     }
-    if wl and not wl.sp:
+    if wl:
         line.update(honesty)     # whole_schedule_steps_per_s, window_bias, tracking: top level, next to `value`
     if wan:
         line.update(wan_extra["line"]())
