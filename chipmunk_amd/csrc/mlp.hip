@@ -631,7 +631,9 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
             if (kb + NST < nkb) load_keys(kb + NST);  // (moving these behind the MFMAs measured 15 % slower)
         }
         MPROF_MARK(2);
-        // Operand fragments by inline-asm LDS reads with hand-counted lgkmcnt: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
+        // Operand fragments by inline-asm LDS reads with hand-counted lgkmcnt (EVERY LDS read of this loop has to stay in asm: one
+        // compiler-visible LDS access added here later brings the drain back and is not counted by the waits below -- tests/test_kernel_audit.py
+        // checks the loop's ISA for it): hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
         // it knows about while an LDS-DMA is in flight (it cannot tell the ring slots apart), which drained the two stages the ring is
         // meant to keep flying.  Reads return in order; a scalar key load in flight only makes a counted wait conservative.
         constexpr int KK = BK / 16;
@@ -915,8 +917,12 @@ int launch_mm1_variant(const Mm1Params &p0, hipStream_t s, bool *cache_updated =
     p.NT = (p.F + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm1_nr") > 0 ? chipmunk_get_option("mm1_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
-    // tail split: WPS workgroups per CU are resident; an XCD's leftover tiles are handed out as sub-tiles at the end of its list
-    const int resident_per_xcd = WPS * device_cu_count() / 8;
+    // tail split: WPS workgroups per CU are resident; an XCD's leftover tiles are handed out as sub-tiles at the end of its list.  The
+    // persistent grid and the split both count on WPS workgroups REALLY fitting a CU: variants whose LDS does not allow it
+    // (<128,64,2,3> / <128,64,2,4>: 3-4 x 64 KiB) get the count their LDS allows -- the output is right either way, the tail balance is not
+    constexpr int WPS_FIT = (160 * 1024 / LDS) < WPS ? (160 * 1024 / LDS) : WPS;
+    static_assert(WPS_FIT >= 1, "a variant's ring must fit the 160 KiB of a CU");
+    const int resident_per_xcd = WPS_FIT * device_cu_count() / 8;
     p.slots_per_xcd = (chipmunk_get_option("mm1_no_split") || NW != 4) ? 0 : resident_per_xcd;
     // persistent grid: the resident slots, or fewer when the launch has fewer tiles than slots (every tile gets its own workgroup)
     const int tiles_per_xcd = ((p.M / BM) * p.NT + 7) / 8;

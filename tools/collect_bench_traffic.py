@@ -48,13 +48,24 @@ WORKLOADS["wan_c5_kbench"] = (["@kbench", "fp8_wan", "mm2_wan", "csp_hunyuan"], 
                               "the bench's own launches: rocprofv3 --pmc crashes on that workload")
 
 
+# round 5: the bench's OWN launches of the Wan2.1 line with the caches resident (no pinned-host copies on side streams -- what crashed the
+# counter passes) and eight of the thirty blocks: the kernels and their operands are the full run's
+WORKLOADS["wan_c5_resident"] = (["--workload", "wan_c5", "--layers", "8", "--steps", "2", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline", "--no-legs"],
+                                {"mm1_fp8_wan": ["mm1_kernel<128, 64, 2, 2, true"], "mm2_wan": ["mm2_kernel"], "csp_128_attn_c3_wan": ["csp96_kernel"],
+                                 "dense_attn_c3_wan": ["attn64_kernel<0>"], "dense_colsum_topk_mask_c3_wan": ["attn64_kernel<3>", "topk_mask_kernel"]},
+                                "bench.py's own launches (wan_c5 with WAN_RESIDENT=1 and 8 of the 30 blocks: 12 heads x 32 760 tokens, fp8 GEMM1 M 32 768 / K 1 536 / "
+                                "F 8 960; the offloaded run's pinned-host copies crash rocprofv3 --pmc)")
+
+
 def one_pass(counter, cmd):
     out = os.path.join(ROOT, "gpurun_out", f"pmcb_{counter}")
     subprocess.run(["rm", "-rf", out])
     env = dict(os.environ, TMPDIR="/tmp")
+    if "--layers" in cmd and "wan_c5" in cmd:
+        env["WAN_RESIDENT"] = "1"
     if "kbench.py" in cmd[0]:
         env.update(KB_HEADS="12", KB_N="32760", KB_COUNT_C3="8832")     # only the csp_hunyuan case reads these: the Wan2.1 sequence
-    subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable] + cmd,
+    subprocess.run(["timeout", "1200", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable] + cmd,
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):

@@ -5,7 +5,8 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 tag=$1; shift
 for wl in "$@"; do
-  python tools/collect_bench_traffic.py $tag $wl > gpurun_out/${tag}_traffic_$wl.txt 2>&1
+  twl=$wl; [ $wl = wan_c5 ] && twl=wan_c5_resident     # (the offloaded Wan run's pinned-host copies crash rocprofv3 --pmc: counters on the resident 8-block run)
+  python tools/collect_bench_traffic.py $tag $twl > gpurun_out/${tag}_traffic_$wl.txt 2>&1
   cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json 2>/dev/null
   arg="--workload $wl"; [ $wl = hunyuan_c3 ] && arg=""
   python bench.py $arg > gpurun_out/${tag}_bench_$wl.json 2> gpurun_out/${tag}_bench_$wl.err
