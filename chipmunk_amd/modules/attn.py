@@ -123,15 +123,16 @@ class SparseDiffAttn(nn.Module):
 
     @torch.compiler.disable
     def _remember_indices(self, inds: Tensor, counts: Tensor) -> None:
-        """``attn.keep_unpacked_indices``: keep what the bit-packed mask just stored unpacks to, while that mask itself stays in
-        HBM -- as ragged rows (``ops.compact_indices``: the kept keys back to back; the padded ``[B, H, G, N]`` int32 tensor is 7 GB per
+        """``attn.keep_unpacked_indices``: keep what the bit-packed mask just stored unpacks to -- while that mask itself stays in
+        HBM, or (``attn.keep_unpacked_indices_offloaded``) also when it travels to pinned host memory -- as ragged rows (``ops.compact_indices``: the kept keys back to back; the padded ``[B, H, G, N]`` int32 tensor is 7 GB per
         HunyuanVideo layer because the text groups keep every key).  One host sync per mask recompute for the total."""
         inv = self.layer_counter.cur_model_invocation_per_step
         old, self._unpacked[inv] = self._unpacked[inv], None
         if old is not None:
             release_resident(old[3])
+        self.storage.indices.suppress_load[inv] = False
         if not (inds.is_cuda and amd_key("attn", "keep_unpacked_indices") and amd_key("attn", "fused_residual")
-                and self.storage.indices.is_resident()):
+                and (self.storage.indices.is_resident() or amd_key("attn", "keep_unpacked_indices_offloaded"))):
             return
         if not reserve_resident(0):
             return
@@ -139,11 +140,15 @@ class SparseDiffAttn(nn.Module):
         nbytes = 4 * flat.numel() + 8 * offsets.numel() + 4 * counts.numel()
         if reserve_resident(nbytes):
             self._unpacked[inv] = (flat, offsets, counts, nbytes)
+            # the sparse steps read these rows: a mask that went to the host need not come back for them
+            # (without recompute_mask the full steps unpack the stored mask themselves: it has to come back then)
+            self.storage.indices.suppress_load[inv] = (not self.storage.indices.is_resident()) and bool(GLOBAL_CONFIG["attn"]["recompute_mask"])
 
     def _kept_indices(self):
         """(flat indices, offsets, counts) of the current model invocation if they were kept and their mask is still resident."""
         kept = self._unpacked[self.layer_counter.cur_model_invocation_per_step]
-        if kept is not None and GLOBAL_CONFIG["attn"]["should_compress_indices"] and self.storage.indices.is_resident():
+        if kept is not None and GLOBAL_CONFIG["attn"]["should_compress_indices"] and (
+                self.storage.indices.is_resident() or amd_key("attn", "keep_unpacked_indices_offloaded")):
             return kept[:3]
         return None
 

@@ -103,6 +103,10 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     # (indices, counts) it unpacks to -- compacted to the widest row, 0.54 GB per HunyuanVideo layer, counted against hbm_budget_gb --
     # instead of re-deriving them from the bits in every sparse step (0.48 ms per layer)
     "attn.keep_unpacked_indices": True,
+    # ... and keep those ragged index rows in HBM (against hbm_budget_gb) even when the bit-packed mask itself travels to pinned host memory
+    # (offloading.attn.indices without keep_resident_if_fits): the rows of a Wan2.1 layer are 27 MB, re-deriving them from the bits costs
+    # 92 us per layer and invocation in every sparse step and writes a 269 MB padded index tensor; the host copy of the mask is then not loaded
+    "attn.keep_unpacked_indices_offloaded": True,
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
@@ -115,6 +119,7 @@ BASE_CONFIG["attn"]["fused_colsum_topk"] = AMD_EXTRA_KEYS["attn.fused_colsum_top
 BASE_CONFIG["mlp"]["fused_scatter"] = AMD_EXTRA_KEYS["mlp.fused_scatter"]
 BASE_CONFIG["attn"]["token_major_output"] = AMD_EXTRA_KEYS["attn.token_major_output"]
 BASE_CONFIG["attn"]["keep_unpacked_indices"] = AMD_EXTRA_KEYS["attn.keep_unpacked_indices"]
+BASE_CONFIG["attn"]["keep_unpacked_indices_offloaded"] = AMD_EXTRA_KEYS["attn.keep_unpacked_indices_offloaded"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
 

@@ -116,6 +116,9 @@ class MaybeOffloadedTensor:
         self.real_shape: List[Optional[torch.Size]] = [None] * n_inv
         self.real_stride: List[Optional[tuple]] = [None] * n_inv   # a dense permuted layout (token-major o) travels as it is
         self._resident: List[bool] = [False] * n_inv
+        # set by a holder's owner when nothing will read the loaded value of an invocation (SparseDiffAttn keeps the index rows a packed mask
+        # unpacks to): load_async then issues no host-to-device copy for it; the next offload() of that invocation clears it
+        self.suppress_load: List[bool] = [False] * n_inv
         self.model_invocation_count = 0
         if self.slot_name not in gpu_tensors:
             gpu_tensors[self.slot_name] = [None] * PIPELINE_DEPTH
@@ -145,6 +148,7 @@ class MaybeOffloadedTensor:
     def offload(self, gpu_tensor: torch.Tensor) -> None:
         key = self.get_cur_model_invocation_key()
         self.real_shape[key] = gpu_tensor.shape
+        self.suppress_load[key] = False
         if self._stays_resident(key, gpu_tensor.numel() * gpu_tensor.element_size()):
             self.gpu_tensor[key] = gpu_tensor
             return
@@ -189,7 +193,8 @@ class MaybeOffloadedTensor:
 
     def needs_host_copy(self) -> bool:
         """True when ``load_async`` will issue a host-to-device copy (something is stored and it is not resident)."""
-        return self.real_shape[self.get_cur_model_invocation_key()] is not None and not self._is_resident_now()
+        key = self.get_cur_model_invocation_key()
+        return self.real_shape[key] is not None and not self._is_resident_now() and not self.suppress_load[key]
 
     @torch.compiler.disable
     def load_async(self, gate: bool = True) -> Optional[torch.Tensor]:
@@ -200,6 +205,8 @@ class MaybeOffloadedTensor:
             return None
         if self._is_resident_now():
             return self.gpu_tensor[key]
+        if self.suppress_load[key]:
+            return None
         slot = gpu_tensors[self.slot_name][self.layer_key]
         stride = self.real_stride[key]
         if slot is None or slot.shape != shape or slot.stride() != stride or slot.dtype != self.cpu_buf[key].dtype:

@@ -111,7 +111,7 @@ def test_ragged_index_rows(dev, H, N, keep):
         assert _is_token_major(b) and torch.equal(a, b)
 
 
-def _run_hunyuan_schedule(dev, token_major, keep_unpacked, resident, steps=13):
+def _run_hunyuan_schedule(dev, token_major, keep_unpacked, resident, steps=13, keep_offloaded=True):
     import chipmunk_amd  # noqa: F401
     from chipmunk_amd.modules import SparseDiffAttn
     from chipmunk_amd.util import config as cfgmod
@@ -126,6 +126,7 @@ def _run_hunyuan_schedule(dev, token_major, keep_unpacked, resident, steps=13):
     cfg["step_caching"]["is_enabled"] = False
     cfg["attn"]["token_major_output"] = token_major
     cfg["attn"]["keep_unpacked_indices"] = keep_unpacked
+    cfg["attn"]["keep_unpacked_indices_offloaded"] = keep_offloaded
     cfg["offloading"]["keep_resident_if_fits"] = resident
     ot.gpu_tensors.clear()
     chipmunk_amd.ops.manual_seed(9)     # the 1 % random keys of the mask step (counter-based hash)
@@ -172,11 +173,14 @@ def test_layout_and_kept_indices_change_nothing_over_a_schedule(dev):
     new, kept, width, N, booked = _run_hunyuan_schedule(dev, True, True, True)
     assert kept == 3 and all(n == need + 64 for n, need in width), "three sparse layers keep ragged index rows: the kept keys, no more"
     assert booked > 4 * sum(n for n, _ in width), "the kept rows are booked against the HBM budget"
-    off, kept_off, _, _, _ = _run_hunyuan_schedule(dev, True, True, False)
-    assert kept_off == 0, "a mask that travels to the host is unpacked where it lands"
+    off, kept_off, _, _, _ = _run_hunyuan_schedule(dev, True, True, False, keep_offloaded=False)
+    assert kept_off == 0, "attn.keep_unpacked_indices_offloaded off: a mask that travels to the host is unpacked where it lands"
+    off_kept, kept_off2, _, _, _ = _run_hunyuan_schedule(dev, True, True, False)
+    assert kept_off2 == 3, "... on (the default): the index rows stay in HBM while the mask and the output cache go through the host"
     off_ref, _, _, _, _ = _run_hunyuan_schedule(dev, False, True, False)
-    assert len(ref) == len(new) == len(off) == 65
-    for i, (a, b, c, d) in enumerate(zip(ref, new, off, off_ref)):
+    assert len(ref) == len(new) == len(off) == len(off_kept) == 65
+    for i, (a, b, c, d, e) in enumerate(zip(ref, new, off, off_ref, off_kept)):
         assert torch.equal(a, b), f"resident, layer call {i}"
         assert torch.equal(a, c), f"offloaded, layer call {i}"
         assert torch.equal(a, d), f"offloaded contiguous, layer call {i}"
+        assert torch.equal(a, e), f"offloaded, index rows kept, layer call {i}"

@@ -213,7 +213,8 @@ def build_wan(dev, args, timer):
             "layers": L,
             "attention": "SparseDiffAttn, configs/wan_c5.yml (top 10 % + 1 % random + 5^3 local voxels, full steps 0, 1, 10k, bit-packed masks)",
             "mlp": "SparseDiffMlp, fp8 e4m3 GEMM1 (chipmunk.csp_mlp_mm1_fp8 over F8Linear), bf16 GEMM2; top 30 % + 5 % random columns, full at 10k",
-            "caches": "attention caches + masks through pinned host memory (hipHostMalloc, side-stream copies one block ahead)"
+            "caches": "attention caches + masks through pinned host memory (hipHostMalloc, side-stream copies one block ahead); the ragged index rows the "
+                      "masks unpack to stay in HBM (attn.keep_unpacked_indices_offloaded: 27 MB per block and invocation)"
                       if not G["offloading"]["keep_resident_if_fits"] else "resident in HBM",
             "step_caching": bool(G["step_caching"]["is_enabled"]), "static_mask_init_s": round(static_mask_s, 2)}
 
