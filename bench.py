@@ -875,7 +875,8 @@ class Hunyuan:
         mods = [a for l in self.layers for a in l[0] if a.storage.out_cache.cpu_buf[0] is not None]
         if not mods:
             return None
-        per_step = sum(b.numel() * b.element_size() for a in mods for b in (a.storage.out_cache.cpu_buf[0], a.storage.indices.cpu_buf[0]) if b is not None)
+        per_step = sum(h.cpu_buf[0].numel() * h.cpu_buf[0].element_size() for a in mods for h in (a.storage.out_cache, a.storage.indices)
+                       if h.cpu_buf[0] is not None and not h.suppress_load[0])    # (masks whose index rows stay in HBM are not read back)
         host = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
         devb = torch.empty(1 << 30, dtype=torch.uint8, device=self.dev)
         rates = {}

@@ -205,7 +205,8 @@ def build_wan(dev, args, timer):
         per_step = 0
         for a in mods:
             for holder in (a.storage.out_cache, a.storage.indices):
-                per_step += sum(b.numel() * b.element_size() for b in holder.cpu_buf if b is not None)
+                # (a mask whose index rows are kept in HBM is not read back: attn.keep_unpacked_indices_offloaded)
+                per_step += sum(b.numel() * b.element_size() for b, skip in zip(holder.cpu_buf, holder.suppress_load) if b is not None and not skip)
         return per_step, len(mods)
 
     desc = {"workload": f"wan_c5: Wan2.1 T2V 1.3B 832x480x81, {N} tokens, 12 heads x 128, dim 1536, ffn 8960, {L} blocks, "
