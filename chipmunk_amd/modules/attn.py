@@ -155,6 +155,13 @@ class SparseDiffAttn(nn.Module):
     def _stored_indices(self, multiple_of: int, bm: int):
         cfg = GLOBAL_CONFIG["attn"]
         if cfg["should_compress_indices"]:
+            inv = self.layer_counter.cur_model_invocation_per_step
+            if self.storage.indices.suppress_load[inv]:
+                # the kept index rows were expected to serve this step and the mask's host copy was not brought back (configuration changed in
+                # between): fetch it now, on the spot
+                self.storage.indices.suppress_load[inv] = False
+                self.storage.indices.load_async()
+                self.storage.indices.load_async_wait()
             packed = self.storage.get_indices()
             shape = self.mask_shape[self.layer_counter.cur_model_invocation_per_step]
             if amd_key("attn", "fused_packed_mask_to_indices") and packed.is_cuda and shape[-1] % 8 == 0:

@@ -184,3 +184,57 @@ def test_layout_and_kept_indices_change_nothing_over_a_schedule(dev):
         assert torch.equal(a, c), f"offloaded, layer call {i}"
         assert torch.equal(a, d), f"offloaded contiguous, layer call {i}"
         assert torch.equal(a, e), f"offloaded, index rows kept, layer call {i}"
+
+
+def test_suppressed_mask_load_is_fetched_on_demand(dev):
+    """attn.keep_unpacked_indices_offloaded keeps the index rows in HBM and does not bring the offloaded mask back; if the kept rows cannot serve a
+    sparse step after all (here: attn.fused_residual switched off in between), the module fetches the mask's host copy on the spot and the step
+    gives the same bits as a run that never kept the rows."""
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd.modules import SparseDiffAttn
+    from chipmunk_amd.util import config as cfgmod
+    from chipmunk_amd.util import layer_counter as lc
+    from chipmunk_amd.util.layer_counter import LayerCounter
+    from chipmunk_amd.util.storage import offloaded_tensor as ot
+
+    def run(keep_offloaded, switch_off_at):
+        cfgmod.reset_to_base()
+        lc.singleton.__init__(0, 0)
+        cfgmod.load_from_file(os.path.join(ROOT, "configs", "hunyuan_c3.yml"))
+        cfg = cfgmod.GLOBAL_CONFIG
+        cfg["steps"] = 50
+        cfg["step_caching"]["is_enabled"] = False
+        cfg["attn"]["first_n_dense_layers"] = 0
+        cfg["attn"]["keep_unpacked_indices_offloaded"] = keep_offloaded
+        cfg["offloading"]["keep_resident_if_fits"] = False
+        ot.gpu_tensors.clear()
+        chipmunk_amd.ops.manual_seed(9)
+        torch.manual_seed(9)
+        H, vid, txt = 2, (4, 12, 16), 64
+        N = vid[0] * vid[1] * vid[2] + txt
+        g = torch.Generator(device=dev).manual_seed(21)
+        q0, k0, v0, dq = [torch.randn(1, H, N, 128, device=dev, generator=g) for _ in range(4)]
+        num, counter = LayerCounter.build_for_layer(is_attn_sparse=True)
+        layer = SparseDiffAttn(num, counter)
+        layer.initialize_static_mask(vid, txt, H, dev)
+        outs, suppressed = [], []
+        with torch.no_grad():
+            for step in range(5):
+                if step == switch_off_at:
+                    cfg["attn"]["fused_residual"] = False
+                if step > 0:
+                    layer.storage.load_async()
+                    layer.storage.load_async_wait()
+                suppressed.append(bool(layer.storage.indices.suppress_load[0]))
+                outs.append(layer((q0 + 0.03 * step * dq).to(torch.bfloat16), k0.to(torch.bfloat16), v0.to(torch.bfloat16)).contiguous().clone())
+                layer.storage.complete_cur_layer()
+        torch.cuda.synchronize()
+        cfgmod.reset_to_base()
+        lc.singleton.__init__(0, 0)
+        return outs, suppressed
+
+    ref, sup_ref = run(False, 3)
+    got, sup = run(True, 3)
+    assert not any(sup_ref) and sup[2] and sup[3], (sup_ref, sup)      # steps 2, 3 are sparse: the mask's load was suppressed ...
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f"step {i}"                          # ... and step 3 (no fused residual any more) fetched it on demand
