@@ -113,7 +113,7 @@ def build_wan(dev, args, timer):
 
     fused_rowwise = bench.HunyuanBlock.fused_rowwise
     ones = torch.ones(HID, **bf)
-    a_pad = torch.zeros(M, HID, **bf)
+    y_pad = torch.zeros(M, HID, **bf)
 
     def ln_mod(x, shift, scale):
         if fused_rowwise:                                    # LayerNorm + modulate in one pass (chipmunk.residual_ln_modulate)
@@ -135,9 +135,11 @@ def build_wan(dev, args, timer):
             o = bench.flash_sdpa(q, k, v)
         else:
             o = ops_pkg.dense_attn(q, k, v)[0]
-        a = a_pad                              # [M, HID] with a zero tail: the N attended rows copied in (F.pad would fill all of it first)
-        a[:N].copy_(tokens_first(o))
-        x = torch.addcmul(x, m[2], torch.addmm(blk["o"].bias, a, blk["o"].weight.t()))
+        # output projection of the N attended rows straight into the first N rows of an [M, HID] buffer; the 8 padding rows of a zero-padded input
+        # would come out as the bias (F.pad of the attention output + GEMM over M rows: a fill and a copy of 100 MB per block in front of it)
+        torch.addmm(blk["o"].bias, tokens_first(o), blk["o"].weight.t(), out=y_pad[:N])
+        y_pad[N:] = blk["o"].bias
+        x = torch.addcmul(x, m[2], y_pad)
         # cross-attention over the text tokens (dense, 512 keys).  q, k, v are the strided head views of the projections' outputs.  The library
         # comparator (how == "sdpa") keeps torch's flash SDPA here too; the other two loops call chipmunk.dense_attn on the views, with the
         # output token-major so that the `b h s d -> s (h d)` in front of the output projection is a view (AOTriton's kernel runs this
