@@ -59,6 +59,23 @@ extern "C" int chipmunk_attn_prof_read(unsigned long long *out) {
 #define PROF_ABS(i)
 #endif
 
+#ifdef ATTN_TIMELINE
+// Life marks of EVERY workgroup of a gathered launch on the constant 100 MHz clock (s_memrealtime: comparable across CUs and XCDs):
+// tools/attn_timeline.py builds a separate library with -DATTN_TIMELINE.  Slot 0 entry, 1 share located (BAL), then per segment s
+// (2 + 4 s ...): count / Q in registers, loop entered, loop left, segment done; 15 = exit.  Not part of the product build.
+__device__ unsigned long long g_attn_tl[4096 * 16];
+#define TL_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 16) g_attn_tl[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int chipmunk_attn_timeline_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_tl), sizeof(g_attn_tl)) == hipSuccess ? 0 : 2;
+}
+extern "C" int chipmunk_attn_timeline_clear() {
+    static unsigned long long z[4096 * 16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tl), z, sizeof(z)) == hipSuccess ? 0 : 2;
+}
+#else
+#define TL_MARK(i)
+#endif
+
 // Pin a value to this point of the program: the optimiser may neither sink its computation below nor hoist its uses above
 // (the IR passes move pure arithmetic across sched_barrier freely; a hand-placed slice has to materialise where it stands).
 template <typename T>
@@ -103,7 +120,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // exp2(s*c - m*c) * (exp2(m*c) * prev_l) does not depend on the max that centres it, so the pass evaluates it as
 // exp2(s*c + log2(prev_l)) -- one fma, one exp2 and one add per score -- in fp32, without the reference's two
 // intermediate bf16 roundings.  It has its own loop (two key tiles per barrier) right after the prologue.
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false>
+//
+// BAL = the work-balanced launch of short gathered launches (FLUX: 552 near-equal items on 512 resident slots used to be two
+// rounds, the second 8 % full).  The launch's key tiles form one line, item after item; `gridDim.x` persistent workgroups take equal
+// shares of it, cut at tile boundaries, so that an item is shared by at most two workgroups when no item is longer than a share.
+// A workgroup walks its share from the right: first the HEAD of the item that straddles its right border -- the unnormalised
+// (O, m, l) state after those tiles is PUBLISHED, nothing else --, then its whole items, last the TAIL of the item that straddles
+// its left border, which does not start from zero but CONTINUES from the state its left neighbour published: online softmax is a
+// fold over the key tiles, so the continuation is the uncut item's own arithmetic and the normal epilogue follows; there is no
+// merge pass and no partial on the launch's critical path.  The neighbour's head is the first thing it does and the tail the last
+// thing this workgroup does, so the state has been published about (share - item) tiles before it is asked for.
+// Logical workgroup ids come from one atomic counter (HIP promises no dispatch order): a consumer only ever waits for a workgroup
+// that drew its id earlier, i.e. one that is running or done.  The state travels as write-through (sc1) 16-byte stores -> vmcnt(0)
+// -> barrier -> relaxed agent flag, and sc1 loads after one relaxed poll (MI355X_MICROARCH.md, hand-off price list).
+// (ticket region of the library scratch, 16 384 ints: [0, 1536) the plan / split tickets, [4096, 8192) these, [8192, ..) knorm_max's floats)
+constexpr int BAL_CTR = 4096;       // p.tickets[BAL_CTR] = id counter, [BAL_CTR + 1] = workgroups done; both left at zero
+constexpr int BAL_FLAG = 4104;      // p.tickets[BAL_FLAG + L] = "the state for workgroup L is published" (reset by its consumer)
+constexpr int BAL_MIN_TILES = 3;    // no part of a cut item is shorter than this (a part pays the item's fixed costs again)
+constexpr int BAL_MAX_ITEMS = 4096;
+constexpr int BAL_STATE_F4 = 26 * 256;   // float4 per published state: 24 of O, m, l per thread
+
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false, bool BAL = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KEYOFF = (CSONLY ? NST : NST + NSTV) * TILE_BYTES;  // the column-sum pass has no V ring
@@ -120,10 +157,86 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int li = lane & 15, lg = lane >> 4;
     PROF_ABS(0);
 
+    TL_MARK(0);
+    // ---- BAL: draw a logical id, scan the items' tile counts, locate this workgroup's share [item jl tile cl, item jr tile cr)
+    int bal_L = 0, bal_jl = 0, bal_cl = 0, bal_jr = 0, bal_cr = 0;
+    if constexpr (BAL) {
+        int *bs = (int *)cs_acc;   // [0] id, [1..4] jl cl jr cr, [8..11] wave totals
+        if (tid == 0) bs[0] = __hip_atomic_fetch_add(p.tickets + BAL_CTR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = p.B * p.H * p.G, per = (n + 255) >> 8;
+        // an item's length on the line: its key tiles, at least one (an item without keys still has an epilogue to run)
+        auto ntp = [&](int j) {
+            int c = p.counts[j];
+            c = c < 0 ? 0 : (c < p.Nk ? c : p.Nk);
+            const int t = (c + KVT - 1) / KVT;
+            return t > 0 ? t : 1;
+        };
+        const int j0 = tid * per, j1 = j0 + per < n ? j0 + per : n;
+        int loc = 0;
+        for (int j = j0; j < j1; ++j) loc += ntp(j);
+        int incl = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            incl += lane >= d ? t : 0;
+        }
+        if (lane == 63) bs[8 + w] = incl;
+        __syncthreads();
+        int wbase = 0, W = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = bs[8 + i];
+            wbase += i < w ? t : 0;
+            W += t;
+        }
+        bal_L = bs[0];
+        const int nwg = (int)gridDim.x;
+        const int a[2] = {(int)((int64_t)W * bal_L / nwg), (int)((int64_t)W * (bal_L + 1) / nwg)};
+        int pos = wbase + incl - loc;
+        for (int j = j0; j < j1; ++j) {
+            const int t = ntp(j);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (pos <= a[e] && a[e] < pos + t) {
+                    int item = j, off = a[e] - pos;
+                    if (off < BAL_MIN_TILES) off = 0;                      // a cut this close to an item's border moves onto it
+                    else if (t - off < BAL_MIN_TILES) item = j + 1, off = 0;
+                    bs[1 + 2 * e] = item, bs[2 + 2 * e] = off;
+                }
+            pos += t;
+        }
+        if (tid == 0) {
+            if (a[0] >= W) bs[1] = n, bs[2] = 0;
+            if (a[1] >= W) bs[3] = n, bs[4] = 0;
+        }
+        __syncthreads();
+        bal_jl = __builtin_amdgcn_readfirstlane(bs[1]), bal_cl = __builtin_amdgcn_readfirstlane(bs[2]);
+        bal_jr = __builtin_amdgcn_readfirstlane(bs[3]), bal_cr = __builtin_amdgcn_readfirstlane(bs[4]);
+        bal_L = __builtin_amdgcn_readfirstlane(bal_L);
+        __syncthreads();   // (the scratch words are the split path's ticket word and the column-sum partials elsewhere)
+    }
+    // segments, right to left: item jr's tiles [0, cr) if cr > 0, the whole items between, item jl from tile cl
+    TL_MARK(1);
+    int tl_seg = 0;
+    int bal_item = BAL ? (bal_cr > 0 ? bal_jr : bal_jr - 1) : 0;
+    if (BAL && bal_item < bal_jl) bal_item = -1;   // an empty share
+    while (!BAL || bal_item >= 0) {
+    // BAL: everything derived from the thread id is recomputed per segment from an opaque copy -- left alone, the loop-invariant
+    // code motion keeps the epilogue's and the prologue's lane constants alive through the main loop (123 spilled VGPRs)
+    int tid_o = threadIdx.x;
+    if constexpr (BAL) asm volatile("" : "+v"(tid_o));
+    const int tid = tid_o, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const bool bal_publish = BAL && bal_item == bal_jr;                    // (only reached with cr > 0)
+    const bool bal_consume = BAL && bal_item == bal_jl && bal_cl > 0;
+
     int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    if constexpr (BAL) wid0 = bal_item;
     // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
     int sp = 0, nsp = 1, slot0 = 0, tix = 0, wid = wid0;
-    if (!CSONLY && p.plan) {
+    if (BAL) {
+    } else if (!CSONLY && p.plan) {
         const u32x2 entry = *(const u32x2 *)(p.plan + 2 * wid0);   // (one round trip, not two)
         wid = (int)entry[0];
         if (wid < 0) return;
@@ -162,10 +275,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     };
     // an unsliced item starts at key tile 0 whatever its count: the first key tiles' indices are requested before anything else, so
     // that their round trip runs beside the Q rows' (it used to start after the Q loads had been issued: one more serial round trip)
+    const int bal_tb = bal_consume ? bal_cl : 0;   // BAL: the segment's first key tile
     const bool early_keys = GATHER && !CSONLY && sp == 0 && irow.width > 0;
     if (early_keys) {
 #pragma unroll
-        for (int T = 0; T < NST; ++T) issue_keys(T);
+        for (int T = 0; T < NST; ++T) issue_keys(bal_tb + T);
     }
     const __amdgpu_buffer_rsrc_t krsrc = make_rsrc(kbase), vrsrc = make_rsrc(vbase);
     const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;  // row strides in bytes
@@ -197,6 +311,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         count_v = __builtin_amdgcn_readfirstlane(count_v);
     }
     const int count = count_v;
+    TL_MARK(2 + 4 * tl_seg);
     // packed positions >= Nk are masked out by the reference (right_fill, csp_128_attn.cu:314)
     const int valid = count < p.Nk ? count : p.Nk;
     const int ntiles = (valid + KVT - 1) / KVT;
@@ -205,7 +320,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         nsp = nsp < cap ? nsp : cap;
         if (sp >= nsp) return;
     }
-    const int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
+    int tbeg = (int)((int64_t)ntiles * sp / nsp), tend = (int)((int64_t)ntiles * (sp + 1) / nsp);
+    if constexpr (BAL) {
+        tbeg = bal_tb < ntiles ? bal_tb : ntiles;
+        tend = bal_publish && bal_cr < ntiles ? bal_cr : ntiles;
+    }
 
     f32x4 cs_off[3];  // CSONLY: log2(prev_l) of query rows qb*16 + lg*4 + 0..3 (that pass computes S, not S^T)
     if constexpr (CSONLY) {
@@ -257,6 +376,8 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         for (int db = 0; db < 8; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m[3] = {-INFINITY, -INFINITY, -INFINITY};
     float lsum[3] = {0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t bal_rsrc = make_rsrc(BAL ? (const void *)p.ws : (const void *)p.q);
+    constexpr uint32_t BAL_STATE_BYTES = BAL_STATE_F4 * 16;
 
     // ---- prologue: keys of tiles 0..NST-1 synchronously, then the data of tiles 0..NST-2, each group followed by one more
     //      key DMA (the main loop reads a tile's keys one iteration before it issues the tile's data: keys run 7 ahead)
@@ -348,11 +469,48 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         return;
     }
 
+    if constexpr (BAL) {
+        if (bal_consume) {
+            // the left neighbour's state for this item: one lane polls (relaxed, sleeping), then every thread reads its 26 pieces
+            // with sc1 loads (the producer stored sc1: no acquire fence needed) and waits them out with vmcnt(0) -- the tile DMAs
+            // issued above are waited for with them; register loads under a counted wait must not have DMAs behind them
+            if (tid == 0 && !(p.probe & 32)) {
+                int32_t *flag = p.tickets + BAL_FLAG + bal_L;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+                __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            }
+            __syncthreads();
+            const uint32_t sb = (uint32_t)bal_L * BAL_STATE_BYTES + (uint32_t)tid * 16u;
+            if (!(p.probe & 16))   // (timing probes: 16 = no state traffic, 32 = no flag wait either; results are then wrong)
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                for (int db = 0; db < 8; ++db)
+                    o[qb][db] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bal_rsrc, sb + (qb * 8 + db) * 4096, 0, 16));
+            const f32x4 ms = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bal_rsrc, sb + 24 * 4096, 0, 16));
+            const f32x4 ls = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bal_rsrc, sb + 25 * 4096, 0, 16));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) m[qb] = ms[qb], lsum[qb] = ls[qb];
+        }
+    }
     // accumulate forms of an unsplit item with work to do: the epilogue's base rows are fetched ahead of the drain tile
-    const bool early_base = INPLACE && nsp == 1 && tend > tbeg;
+    // (BAL: read in the epilogue's store loop -- held in registers from here they spill in this form of the kernel, and a spill waits
+    // the loads out on the spot)
+    const bool early_base = INPLACE && !BAL && nsp == 1 && tend > tbeg;
+    const bool base_before_drain = early_base;
     u32x4 base[INPLACE ? QW * 256 / 1024 : 1];
+    auto fetch_base = [&]() {
+#pragma unroll
+        for (int i = 0; i < QW * 256 / 1024; ++i) {
+            const int qrow = row0 + i * 4 + (lane >> 4);
+            base[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (qrow < p.Nq) base[i] = *(const u32x4 *)(p.o_in + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + (lane & 15) * 8);
+        }
+    };
     PROF_DECL;
     PROF_ABS(2);
+    TL_MARK(3 + 4 * tl_seg);
     PROF_START();
     {
         // ---- pipelined loop: PV runs ONE TILE BEHIND QK^T.  Iteration t: S(t) = K(t).Q^T, then ONE scheduling region holding
@@ -500,9 +658,27 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             // ---- first tile: the reference point is its own maximum (exact), nothing to rescale
             tile_sync(tbeg);
             qk_tile(tbeg);
+            if (BAL && bal_consume) {
+                // a continued item: the reference point is the published one, moved (with the rescale) only if this tile outgrows the lag
+                float mx[3];
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) mx[qb] = max_rows(tile_max(qb));
+                constexpr float LAG_RAW0 = MAX_LAG / SCALE_LOG2E;
+                if (!__all(mx[0] <= m[0] + LAG_RAW0 && mx[1] <= m[1] + LAG_RAW0 && mx[2] <= m[2] + LAG_RAW0)) {
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) {
+                        const float m_new = max2(m[qb], mx[qb]);
+                        const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
+                        lsum[qb] *= a;
+                        m[qb] = m_new;
+#pragma unroll
+                        for (int db = 0; db < 8; ++db) o[qb][db] *= a;
+                    }
+                }
+            }
 #pragma unroll
             for (int qb = 0; qb < 3; ++qb) {
-                m[qb] = max_rows(tile_max(qb));
+                if (!(BAL && bal_consume)) m[qb] = max_rows(tile_max(qb));
                 nmsc[qb] = -m[qb] * SCALE_LOG2E;
                 exp_block(qb, nmsc[qb]);
                 row_sum(qb);
@@ -591,20 +767,14 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
             // accumulate forms: the base rows in the epilogue's layout (12 x 16 bytes per lane), requested before the drain tile
             if constexpr (INPLACE) {
-                if (early_base) {
-#pragma unroll
-                    for (int i = 0; i < QW * 256 / 1024; ++i) {
-                        const int qrow = row0 + i * 4 + (lane >> 4);
-                        base[i] = (u32x4){0u, 0u, 0u, 0u};
-                        if (qrow < p.Nq) base[i] = *(const u32x4 *)(p.o_in + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + (lane & 15) * 8);
-                    }
-                }
+                if (base_before_drain) fetch_base();
             }
             pv_mfmas(tend - 1);
         }
     }
     PROF_END(w, tend - tbeg);
     PROF_ABS(3);
+    TL_MARK(4 + 4 * tl_seg);
 
     if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
@@ -660,6 +830,21 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
         }
     }
+    if (BAL && bal_publish) {
+        // ---- the head of a cut item: the state goes to the right neighbour (slot L + 1), write-through; no epilogue
+        const uint32_t sb = (uint32_t)(bal_L + 1) * BAL_STATE_BYTES + (uint32_t)tid * 16u;
+        if (!(p.probe & 16))
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[qb][db]), bal_rsrc, sb + (qb * 8 + db) * 4096, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){m[0], m[1], m[2], 0.f}), bal_rsrc, sb + 24 * 4096, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){lsum[0], lsum[1], lsum[2], 0.f}), bal_rsrc, sb + 25 * 4096, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave's stores have been acknowledged (and everybody is done with the rings and the key ring)
+        if (tid == 0 && !(p.probe & 32)) __hip_atomic_store(p.tickets + BAL_FLAG + bal_L + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     // ---- epilogue: O = O^T / l.  A lane holds 4 consecutive d (8 bytes) of one query row per (qb, db): stored as they stand that is
     //      24 eight-byte accesses per lane, each instruction touching 16 rows x 32 bytes (and as many loads for the accumulate forms):
     //      the store tail was 15.8 k of a FLUX item's 114 k cycles (tools/attn_prof.py).  The wave's 48 x 128 bf16 results go through
@@ -712,6 +897,23 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the mark is taken once the stores have left
 #endif
     PROF_ABS(4);
+    }
+    TL_MARK(5 + 4 * tl_seg);
+    ++tl_seg;
+    if constexpr (!BAL) break;
+    bal_item = bal_item > bal_jl ? bal_item - 1 : -1;
+    }   // segments
+    TL_MARK(15);
+    if constexpr (BAL) {
+        // the last workgroup out leaves the two counters at zero for the next launch
+        if (tid == 0) {
+            const int done = __hip_atomic_fetch_add(p.tickets + BAL_CTR + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == (int)gridDim.x - 1) {
+                __hip_atomic_store(p.tickets + BAL_CTR, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.tickets + BAL_CTR + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // Work plan for ragged key counts.  HunyuanVideo's text / tail query groups keep ALL 119k keys (13x a normal group); a
@@ -880,6 +1082,28 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
             grid = cap;
             if (want96) return chipmunk_csp96_launch(pp, INPLACE ? 1 : 0, (int)grid, stream);
             if (want64) return chipmunk_csp64_launch(pp, INPLACE ? 1 : 0, (int)grid, stream);
+        }
+    }
+    // Work-balanced launch (BAL, see attn_kernel): gathered launches of a few rounds whose last round would be poorly filled.
+    // Option attn_balanced: 1 = always (tests), 3 = by shape, 0 / 2 = never (measured slower than the two-round launch so far, see DESIGN).
+    if constexpr (GATHER && !CSONLY && !WRITE_L) {
+        const int ob = chipmunk_get_option("attn_balanced");
+        const int64_t slots = wg_per_cu * (int64_t)device_cu_count();
+        const int64_t rounds = (nblocks + slots - 1) / slots;
+        const bool by_shape = nblocks > slots && rounds <= 8 && (rounds * slots - nblocks) * 4 >= slots && nblocks <= BAL_MAX_ITEMS;
+        if (!pp.plan && !pp.xcd_chunks && (ob == 1 || (ob == 3 && by_shape)) && slots <= 4000) {
+            const int64_t nwg = nblocks < slots ? nblocks : slots;
+            unsigned char *sc = (unsigned char *)chipmunk_scratch(stream, TICKET_BYTES + (size_t)(nwg + 1) * BAL_STATE_F4 * sizeof(f32x4));
+            if (sc) {
+                auto kb = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY, true>;
+                static uint64_t lds_set_b = 0;
+                ensure_dynamic_lds((const void *)kb, ATTN_LDS_BYTES, lds_set_b);
+                pp.tickets = (int32_t *)sc;
+                pp.ws = (float *)(sc + TICKET_BYTES);
+                hipLaunchKernelGGL(kb, dim3((unsigned)nwg), dim3(256), ATTN_LDS_BYTES, stream, pp);
+                CM_LAUNCH_CHECK();
+                return CHIPMUNK_OK;
+            }
         }
     }
     // Key-split tail.  Workgroups are dispatched in block order as the 2-per-CU slots free up; with near-equal items

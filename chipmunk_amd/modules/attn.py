@@ -28,7 +28,7 @@ from ..ops.voxel import get_local_indices_with_text
 from ..util.config import GLOBAL_CONFIG, amd_key
 from ..util.layer_counter import LayerCounter
 from ..util.storage import AttnStorage
-from ..util.storage.offloaded_tensor import release_resident, reserve_resident
+from ..util.storage.offloaded_tensor import release_kept_offloaded, release_resident, reserve_kept_offloaded, reserve_resident
 
 # shared by all layers, initialised from the sequence shape (reference attn.py:12-14)
 singleton_static_mask: Optional[Tensor] = None
@@ -56,7 +56,7 @@ class SparseDiffAttn(nn.Module):
         self.query_group_offset = query_group_offset
         self.storage = AttnStorage(layer_num, init_names=["indices", "out_cache"], slot=storage_slot)
         self.mask_shape = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]
-        self._unpacked = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]   # (indices, counts, bytes booked)
+        self._unpacked = [None] * GLOBAL_CONFIG["num_model_invocations_per_inference_step"]   # (indices, offsets, counts, bytes booked, booked in offload mode)
 
     # ------------------------------------------------------------------------------------------ static mask
     def initialize_static_mask(self, seq_shape: Tuple, txt_len: int, local_heads_num: int, device: torch.device):
@@ -112,8 +112,14 @@ class SparseDiffAttn(nn.Module):
         new resolution -- would otherwise leave its share booked for the life of the process)."""
         for inv, old in enumerate(self._unpacked):
             if old is not None:
-                release_resident(old[3])
+                self._release_kept(old)
                 self._unpacked[inv] = None
+
+    @staticmethod
+    def _release_kept(kept) -> None:
+        release_resident(kept[3])
+        if kept[4]:
+            release_kept_offloaded(kept[3])
 
     def __del__(self):
         try:
@@ -129,8 +135,8 @@ class SparseDiffAttn(nn.Module):
         inv = self.layer_counter.cur_model_invocation_per_step
         old, self._unpacked[inv] = self._unpacked[inv], None
         if old is not None:
-            release_resident(old[3])
-        self.storage.indices.suppress_load[inv] = False
+            self._release_kept(old)
+        self.storage.indices.suppress_current(False)
         if not (inds.is_cuda and amd_key("attn", "keep_unpacked_indices") and amd_key("attn", "fused_residual")
                 and (self.storage.indices.is_resident() or amd_key("attn", "keep_unpacked_indices_offloaded"))):
             return
@@ -138,11 +144,18 @@ class SparseDiffAttn(nn.Module):
             return
         flat, offsets = ops.compact_indices(inds, counts)
         nbytes = 4 * flat.numel() + 8 * offsets.numel() + 4 * counts.numel()
-        if reserve_resident(nbytes):
-            self._unpacked[inv] = (flat, offsets, counts, nbytes)
-            # the sparse steps read these rows: a mask that went to the host need not come back for them
-            # (without recompute_mask the full steps unpack the stored mask themselves: it has to come back then)
-            self.storage.indices.suppress_load[inv] = (not self.storage.indices.is_resident()) and bool(GLOBAL_CONFIG["attn"]["recompute_mask"])
+        # rows whose mask goes to the host also count against the small dedicated budget (attn.kept_indices_offloaded_budget_gb)
+        off_mode = not self.storage.indices.is_resident()
+        if off_mode and not reserve_kept_offloaded(nbytes):
+            return
+        if not reserve_resident(nbytes):
+            if off_mode:
+                release_kept_offloaded(nbytes)
+            return
+        self._unpacked[inv] = (flat, offsets, counts, nbytes, off_mode)
+        # the sparse steps read these rows: a mask that went to the host need not come back for them
+        # (without recompute_mask the full steps unpack the stored mask themselves: it has to come back then)
+        self.storage.indices.suppress_current(off_mode and bool(GLOBAL_CONFIG["attn"]["recompute_mask"]))
 
     def _kept_indices(self):
         """(flat indices, offsets, counts) of the current model invocation if they were kept and their mask is still resident."""
@@ -155,11 +168,10 @@ class SparseDiffAttn(nn.Module):
     def _stored_indices(self, multiple_of: int, bm: int):
         cfg = GLOBAL_CONFIG["attn"]
         if cfg["should_compress_indices"]:
-            inv = self.layer_counter.cur_model_invocation_per_step
-            if self.storage.indices.suppress_load[inv]:
+            if self.storage.indices.is_suppressed():
                 # the kept index rows were expected to serve this step and the mask's host copy was not brought back (configuration changed in
                 # between): fetch it now, on the spot
-                self.storage.indices.suppress_load[inv] = False
+                self.storage.indices.suppress_current(False)
                 self.storage.indices.load_async()
                 self.storage.indices.load_async_wait()
             packed = self.storage.get_indices()

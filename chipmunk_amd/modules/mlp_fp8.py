@@ -126,8 +126,11 @@ class F8Linear(nn.Module):
             self.input_scale = amax_to_scale(amax, self.input_max_value)
             self.input_scale_reciprocal = self.input_scale.reciprocal()
         if (x.is_cuda and x.dtype == torch.bfloat16 and self.input_float8_dtype == torch.float8_e4m3fn and x.numel() % 8 == 0
-                and self.input_scale.dtype == torch.float32 and amd_key("mlp", "fused_fp8_quantize")):
+                and self.input_scale.dtype == torch.float32 and self.input_scale.is_cuda and self.input_scale.dim() == 0
+                and amd_key("mlp", "fused_fp8_quantize")):
             # the three elementwise kernels below as one pass, bit-identical (tests/test_gpu_mlp.py::test_quantize_fp8_matches_the_torch_chain)
+            # -- for a 0-dim device scale only: a shape-[1] scale makes torch's `x * scale` a single fp32 rounding, a host scale
+            # cannot be read by the kernel; both take the torch chain below
             return torch.ops.chipmunk.quantize_fp8(x, self.input_scale.reshape(1), float(self.input_max_value))
         return to_fp8_saturated(x, self.input_scale, self.input_max_value).to(self.input_float8_dtype)
 

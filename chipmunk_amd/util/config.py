@@ -107,6 +107,10 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     # (offloading.attn.indices without keep_resident_if_fits): the rows of a Wan2.1 layer are 27 MB, re-deriving them from the bits costs
     # 92 us per layer and invocation in every sparse step and writes a 269 MB padded index tensor; the host copy of the mask is then not loaded
     "attn.keep_unpacked_indices_offloaded": True,
+    # ... up to this many GB over all layers when the masks are NOT resident (a run that asked for its caches on the host keeps at most
+    # this much derived state in HBM: HunyuanVideo's rows would be 32 GB, Wan2.1's are 1.6 GB); beyond it a layer re-derives its rows
+    # from the bits as the reference does.  With the masks resident the rows count against hbm_budget_gb only.
+    "attn.kept_indices_offloaded_budget_gb": 8.0,
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
@@ -120,6 +124,7 @@ BASE_CONFIG["mlp"]["fused_scatter"] = AMD_EXTRA_KEYS["mlp.fused_scatter"]
 BASE_CONFIG["attn"]["token_major_output"] = AMD_EXTRA_KEYS["attn.token_major_output"]
 BASE_CONFIG["attn"]["keep_unpacked_indices"] = AMD_EXTRA_KEYS["attn.keep_unpacked_indices"]
 BASE_CONFIG["attn"]["keep_unpacked_indices_offloaded"] = AMD_EXTRA_KEYS["attn.keep_unpacked_indices_offloaded"]
+BASE_CONFIG["attn"]["kept_indices_offloaded_budget_gb"] = AMD_EXTRA_KEYS["attn.kept_indices_offloaded_budget_gb"]
 
 GLOBAL_CONFIG: Dict[str, Any] = copy.deepcopy(BASE_CONFIG)
 

@@ -66,6 +66,24 @@ def release_resident(nbytes: int) -> None:
     _resident_bytes = max(0, _resident_bytes - nbytes)
 
 
+_kept_offloaded_bytes = 0
+
+
+def reserve_kept_offloaded(nbytes: int) -> bool:
+    """The smaller, dedicated budget (``attn.kept_indices_offloaded_budget_gb``) for index rows kept in HBM while their mask
+    travels to the host: offload mode keeps its footprint bounded whatever ``hbm_budget_gb`` says."""
+    global _kept_offloaded_bytes
+    if _kept_offloaded_bytes + nbytes > float(amd_key("attn", "kept_indices_offloaded_budget_gb")) * (1 << 30):
+        return False
+    _kept_offloaded_bytes += nbytes
+    return True
+
+
+def release_kept_offloaded(nbytes: int) -> None:
+    global _kept_offloaded_bytes
+    _kept_offloaded_bytes = max(0, _kept_offloaded_bytes - nbytes)
+
+
 def _side_stream(kind: str) -> "torch.cuda.Stream":
     key = (kind, torch.cuda.current_device())
     if key not in _streams:
@@ -182,9 +200,20 @@ class MaybeOffloadedTensor:
         policy) -- in-place consumers must then work on a copy; False when it returns a pipeline slot refilled from host."""
         return self._is_resident_now()
 
+    def suppress_current(self, flag: bool) -> None:
+        """Skip (or stop skipping) the host-to-device copy of the CURRENT model invocation's tensor; keyed like every other
+        per-invocation field of the holder, so the flag cannot end up on another invocation than the loads it steers."""
+        self.suppress_load[self.get_cur_model_invocation_key()] = bool(flag)
+
+    def is_suppressed(self) -> bool:
+        return self.suppress_load[self.get_cur_model_invocation_key()]
+
     def get_loaded_value(self) -> Optional[torch.Tensor]:
         if self._is_resident_now():
             return self.gpu_tensor[self.get_cur_model_invocation_key()]
+        assert not self.is_suppressed(), (
+            f"Tensor {self.name} (layer {self.layer_num}): its load was suppressed for this model invocation -- the pipeline slot "
+            "holds another tensor; clear the flag (suppress_current(False)) and load it first")
         slot = gpu_tensors[self.slot_name][self.layer_key]
         assert slot is not None, (
             f"Tensor {self.name} is not loaded yet for layer {self.layer_num}. "
@@ -215,9 +244,11 @@ class MaybeOffloadedTensor:
         side = load_stream()
         if gate:
             side.wait_stream(torch.cuda.current_stream())  # the slot's previous reader (layer - PIPELINE_DEPTH) is done
-            ev = _last_offload_event.get(slot.device.index)
-            if ev is not None:
-                side.wait_event(ev)   # the pinned source was written, and the slot last read, by a device-to-host copy no newer than this
+        # gated or not: the pinned source was written, and the slot last read, by a device-to-host copy no newer than this event (an
+        # offload() between a storage's gate and a later holder's copy re-records it; waiting on a satisfied event costs next to nothing)
+        ev = _last_offload_event.get(slot.device.index)
+        if ev is not None:
+            side.wait_event(ev)
         with torch.cuda.stream(side):
             slot.copy_(self.cpu_buf[key][: slot.numel()].as_strided(shape, stride), non_blocking=True)
             slot.record_stream(side)
