@@ -1044,7 +1044,7 @@ class Hunyuan:
             e1.record()
             e1.synchronize()
             rates[name + "_GBps"] = 4 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        return {"h2d_bytes_per_sparse_step": per_step, "modules_offloaded": len(mods),
+        return {"h2d_bytes_per_sparse_step": per_step, "pinned_host_bytes_read_per_sparse_step": per_step, "modules_offloaded": len(mods),
                 "h2d_GBps_needed_to_hide": per_step / sparse_step_s / 1e9, **rates,
                 "what": "copies ride two side streams (hipMemcpyAsync from hipHostMalloc memory), one block ahead of the compute"}
 

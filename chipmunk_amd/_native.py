@@ -6,7 +6,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchipmunk_hip.so")
+# CHIPMUNK_HIP_LIB: another build of the same library (tools/probes/mm1_forms/build.sh: the measured-and-not-shipped GEMM forms); set
+# LD_LIBRARY_PATH to its directory as well so that the torch registry binds to the same file
+LIB_PATH = os.environ.get("CHIPMUNK_HIP_LIB") or os.path.join(_HERE, "lib", "libchipmunk_hip.so")
 
 # every symbol include/chipmunk_hip.h declares (tests/test_abi.py checks this list against the header)
 SYMBOLS = [

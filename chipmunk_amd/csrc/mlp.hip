@@ -508,8 +508,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mm1_kernel(const Mm1Params p) {
     }
 }
 
+// The tile shapes and producer / consumer forms measured against the shipped kernels (docs/EXPERIMENTS_r04.md / _r05.md) are
+// not part of the product library: tools/probes/mm1_forms/build.sh compiles this file with -DCHIPMUNK_MM1_PROBES into
+// tools/bin/forms/libchipmunk_hip.so, where options mm1_variant / mm2_variant select them (same parity tests, tests/test_gpu_mlp_forms.py).
+#ifdef CHIPMUNK_MM1_PROBES
 #include "mlp_pc.h"
 #include "mlp_pp.h"
+#endif
 
 // ------------------------------------------------------------------------------------------------ mm2
 struct Mm2Params {
@@ -881,6 +886,7 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
     CM_CHECK(N2 > 0 && N2 % 8 == 0, "mm2: N2 must be a positive multiple of 8 (got %d)", N2);
     CM_CHECK((int64_t)M * F < (1ll << 31) && (int64_t)F * N2 < (1ll << 31), "mm2: M*F or F*N2 too large for 32-bit offsets");
     Mm2Params p = {(const uint16_t *)a, (const uint16_t *)b, (uint16_t *)c, indices, counts, M, F, N2, 0, 0, chipmunk_get_option("mm1_probe")};
+#ifdef CHIPMUNK_MM1_PROBES
     switch (chipmunk_get_option("mm2_variant")) {
         case 1: return launch_mm2_variant<256, 64, 2, 1>(p, s);
         case 2: return launch_mm2_variant<128, 64, 2, 2>(p, s);
@@ -897,10 +903,12 @@ int launch_mm2(const void *a, const void *b, void *c, const int32_t *indices, co
         case 14: return launch_mm2_variant<256, 32, 3, 2>(p, s);  // the 4-wave form of the default
         case 15: return launch_mm2_variant<512, 32, 4, 2, 8>(p, s);  // 128 x 512 tiles, one workgroup per CU, wave tile 64 x 128
         case 16: return launch_mm2_variant<512, 32, 3, 2, 8>(p, s);
-        // 8 waves (2 x 4, 64 x 64 per wave, 4 waves per SIMD) x 2 workgroups per CU: equal to the 4-wave form in
-        // isolation, 2 % faster inside the bench loop (A/B on one box: 170.5 -> 167.3 us, twice)
-        default: return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
+        default: break;
     }
+#endif
+    // 8 waves (2 x 4, 64 x 64 per wave, 4 waves per SIMD) x 2 workgroups per CU: equal to the 4-wave form in
+    // isolation, 2 % faster inside the bench loop (A/B on one box: 170.5 -> 167.3 us, twice)
+    return launch_mm2_variant<256, 32, 3, 2, 8>(p, s);
 }
 
 template <int BN, int BK, int NST, int WPS, bool FP8 = false, int NW = 4>
@@ -944,6 +952,7 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
              "csp_mlp_mm1: operand too large for 32-bit offsets");
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache,
                    (uint16_t *)c, indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache, nullptr, nullptr};
+#ifdef CHIPMUNK_MM1_PROBES
     switch (chipmunk_get_option("mm1_variant")) {
         case 1: return launch_mm1_variant<256, 64, 2, 1>(p, stream, cache_updated);
         case 3: return launch_mm1_variant<128, 64, 3, 1>(p, stream, cache_updated);
@@ -966,8 +975,10 @@ int mm1_entry(const void *a, const void *b, void *c, const void *bias, void *pa_
                 return launch_mm1pp<false>(p, stream);
             }
             [[fallthrough]];
-        default: return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*)
+        default: break;
     }
+#endif
+    return launch_mm1_variant<128, 64, 2, 2>(p, stream, cache_updated);  // measured best (profiles/r01_*); the library's one GEMM1 form
 }
 }  // namespace
 
@@ -1023,8 +1034,10 @@ extern "C" int chipmunk_csp_mlp_mm1_fp8(const void *a, const void *b, void *c, c
     // same tile machinery as the bf16 kernel (buffer-form DMA, tail split, staged epilogue); a k step is 128 fp8 values
     Mm1Params p = {(const uint16_t *)a, (const uint16_t *)b, (const uint16_t *)bias, (uint16_t *)pa_cache, (uint16_t *)c,
                    indices, counts, M, K, F, 0, 0, chipmunk_get_option("mm1_probe"), 0, update_cache == 1 ? 2 : update_cache == 2 ? 1 : 0, scale_a, scale_b};
+#ifdef CHIPMUNK_MM1_PROBES
     if (chipmunk_get_option("mm1_variant") == 10) return launch_mm1_variant<256, 64, 3, 1, true, 8>(p, (hipStream_t)stream);
     if (chipmunk_get_option("mm1_variant") == 20 && K >= 256) return launch_mm1pc<true>(p, (hipStream_t)stream);
     if (chipmunk_get_option("mm1_variant") == 21 && K >= 768) return launch_mm1pp<true>(p, (hipStream_t)stream);
+#endif
     return launch_mm1_variant<128, 64, 2, 2, true>(p, (hipStream_t)stream);
 }

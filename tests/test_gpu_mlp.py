@@ -7,6 +7,14 @@ from helpers import assert_close_bf16, randn_bf16
 
 pytestmark = pytest.mark.gpu
 
+# The library ships ONE GEMM1 and ONE GEMM2 form.  The measured-and-not-shipped forms live in tools/probes/mm1_forms (a build of the
+# same sources with -DCHIPMUNK_MM1_PROBES); tests/test_gpu_mlp_forms.py re-runs this file against that library with CHIPMUNK_MM1_FORMS=1.
+import os as _os
+_FORMS = _os.environ.get("CHIPMUNK_MM1_FORMS") == "1"
+MM1_FORMS = [0, 20, 21] if _FORMS else [0]
+MM1_FORMS_10 = [0, 10, 20, 21] if _FORMS else [0]
+MM2_FORMS = [0, 10, 14] if _FORMS else [0]
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -47,7 +55,7 @@ def test_mm1_known_answer_reversed_identity(dev):
     assert_close_bf16(c, ref.flip(1), what="mm1 vs torch formula")
 
 
-@pytest.mark.parametrize("variant", [0, 20, 21])
+@pytest.mark.parametrize("variant", MM1_FORMS)
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]), (640, 512, 1024, [0, 1024, 136, 512, 8])])
 def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts, variant, request):
     from chipmunk_amd import _native
@@ -67,7 +75,7 @@ def test_mm1_random_indices_and_ragged_counts(dev, M, K, F, counts, variant, req
         assert (c[g * 128:(g + 1) * 128, n:].float() == sentinel).all()
 
 
-@pytest.mark.parametrize("variant", [0, 4, 10, 20, 21])  # 21: producer / consumer form, DMA stream across tiles; 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
+@pytest.mark.parametrize("variant", [0, 4, 10, 20, 21] if _FORMS else [0])  # 21: producer / consumer form, DMA stream across tiles; 0: staged epilogue (fused in-kernel), 4: falls back to the scatter kernel, 10: 8 waves on 128 x 256 tiles, 20: producer / consumer form
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 320, 768, [16, 272, 768]),
                                           (4352, 128, 1024, [1024 - 16 * (g % 5) for g in range(34)]),
                                           (1280, 448, 2048, [2048 - 24 * (g % 7) for g in range(10)])])
@@ -109,7 +117,7 @@ def test_scatter_add(dev, M, F, counts):
     assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "scatter_add must be bit-exact"
 
 
-@pytest.mark.parametrize("variant", [0, 10, 14])  # 0: shipped (8 waves, k step 32); 10: 8 waves, k step 64; 14: 4 waves
+@pytest.mark.parametrize("variant", MM2_FORMS)  # 0: shipped (8 waves, k step 32); 10: 8 waves, k step 64; 14: 4 waves
 @pytest.mark.parametrize("M,F,N2,counts", [(256, 512, 256, [64, 192]), (384, 1024, 384, [512, 8, 328]),
                                            (128, 512, 768, [512])])
 def test_mm2_and_scatter_add(dev, M, F, N2, counts, variant):
@@ -162,7 +170,7 @@ def test_run_e2e_matches_dense_delta(dev):
     assert_close_bf16(out_cache, ref, atol=6e-2, rtol=3e-2, what="sparse step output")
 
 
-@pytest.mark.parametrize("variant", [0, 10, 20, 21])   # 10: 8 waves on 128 x 256 tiles, 20 / 21: producer / consumer forms
+@pytest.mark.parametrize("variant", MM1_FORMS_10)   # 10: 8 waves on 128 x 256 tiles, 20 / 21: producer / consumer forms
 @pytest.mark.parametrize("update_cache", [False, True])
 def test_mm1_fp8_vs_oracle(dev, update_cache, variant, request):
     """BASELINE config C5: fp8 e4m3fn GEMM1 (reference triton/csp_mlp_mm1.py:37-164), Wan-like K = 1536."""
@@ -231,7 +239,7 @@ def test_sparse_mlp_module_fp8_path(dev, fresh_config):
 
 
 @pytest.mark.parametrize("M,K,F,counts", [(256, 256, 1024, [256, 512]), (384, 128, 768, [0, 768, 256]), (512, 1536, 1024, [512, 256, 1024, 768])])
-@pytest.mark.parametrize("variant", [0, 10, 20, 21])
+@pytest.mark.parametrize("variant", MM1_FORMS_10)
 def test_fp8_mm1_scatter_equals_fp8_mm1_then_scatter_add(dev, M, K, F, counts, variant, request):
     """csp_mlp_mm1_fp8_scatter == csp_mlp_mm1_fp8 (update_cache off) followed by csp_scatter_add: bit for bit in the packed deltas
     AND in the activation cache (the fp8 counterpart of the bf16 fusion test above)."""

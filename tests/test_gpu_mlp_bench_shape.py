@@ -15,6 +15,14 @@ from helpers import assert_close_bf16, randn_bf16
 
 pytestmark = pytest.mark.gpu
 
+# The library ships ONE GEMM1 and ONE GEMM2 form.  The measured-and-not-shipped forms live in tools/probes/mm1_forms (a build of the
+# same sources with -DCHIPMUNK_MM1_PROBES); tests/test_gpu_mlp_forms.py re-runs this file against that library with CHIPMUNK_MM1_FORMS=1.
+import os as _os
+_FORMS = _os.environ.get("CHIPMUNK_MM1_FORMS") == "1"
+MM1_FORMS = [0, 20, 21] if _FORMS else [0]
+MM1_FORMS_10 = [0, 10, 20, 21] if _FORMS else [0]
+MM2_FORMS = [0, 10, 14] if _FORMS else [0]
+
 BM, BN, NR, NSUB, WPS = 128, 128, 4, 4, 2     # shipped GEMM1 variant <128, 64, 2, 2>: NSUB = 2 * (BN / 64)
 M, F = 4352, 12288                            # FLUX.1-dev 1280x768: 4096 image + 256 text tokens, mlp hidden 12288
 G = M // BM
@@ -137,7 +145,7 @@ def test_plan_mirror_matches_kernel_and_split_is_taken(dev):
     assert torch.equal(untouched, expect), "the kernel's sub-tile map differs from the host mirror"
 
 
-@pytest.mark.parametrize("variant", [0, 20, 21])   # 20 / 21: the producer / consumer forms (own tile walks: 128 x 256 tiles, 128 x 128 with the DMA
+@pytest.mark.parametrize("variant", MM1_FORMS)   # 20 / 21: the producer / consumer forms (own tile walks: 128 x 256 tiles, 128 x 128 with the DMA
 @pytest.mark.parametrize("top", [4096, F])   # stream across tiles).  4096: the bench's plan (2 iterations + split tail); F: one group keeps every column
 def test_mm1_bench_shape_vs_torch_and_oracle(dev, top, variant, request):  # (96 live column tiles, 408 tiles per XCD = 7 persistent iterations, no split)
     from chipmunk_amd import _native
@@ -194,7 +202,7 @@ def test_mm1_bench_shape_vs_torch_and_oracle(dev, top, variant, request):  # (96
         assert_close_bf16(c[rows], c_ref, what=f"mm1 group {g} (covers {key}) vs oracle")
 
 
-@pytest.mark.parametrize("variant", [0, 20, 21])
+@pytest.mark.parametrize("variant", MM1_FORMS)
 def test_mm1_fp8_split_plan_vs_torch(dev, variant, request):
     from chipmunk_amd import _native
     _native.set_option("mm1_variant", variant)
@@ -279,7 +287,7 @@ def test_producer_consumer_forms_equal_the_shipped_kernel_bit_for_bit_and_run_to
             _native.set_option("mm1_variant", 0)
 
     c0, cache_ref = run(0)
-    for variant in (20, 21):
+    for variant in MM1_FORMS[1:]:
         for rep in range(10):
             c, cache = run(variant)
             assert torch.equal(c.view(torch.int16), c0.view(torch.int16)), f"variant {variant}, launch {rep}: packed deltas differ from the shipped kernel's"

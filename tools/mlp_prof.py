@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_mlpprof.so")
 def build():
     src = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "rowwise.hip", "capi.hip")]
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMLP_PROF", "-o", LIB] + src)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMLP_PROF", "-DCHIPMUNK_MM1_PROBES", "-I" + os.path.join(ROOT, "tools", "probes", "mm1_forms"), "-o", LIB] + src)
 
 
 def main():

@@ -334,6 +334,8 @@ __global__ __launch_bounds__(512, 1) void mm1pc_kernel(const Mm1Params p) {
 
 template <bool FP8>
 int launch_mm1pc(const Mm1Params &p0, hipStream_t s) {
+    // the precondition lives with the kernel, not with the dispatch switch: k steps of 128 bytes of every row
+    CM_CHECK((int)((uint32_t)p0.K * (FP8 ? 1 : 2) / 128) >= 2, "launch_mm1pc: needs at least two k steps (the cache block's pieces ride the last two)");
     auto kern = mm1pc_kernel<FP8>;
     static uint64_t lds_set = 0;
     ensure_dynamic_lds((const void *)kern, PC_LDS, lds_set);

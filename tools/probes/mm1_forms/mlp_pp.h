@@ -375,6 +375,8 @@ __global__ __launch_bounds__(512, 1) void mm1pp_kernel(const Mm1Params p) {
 
 template <bool FP8>
 int launch_mm1pp(const Mm1Params &p0, hipStream_t s) {
+    // the precondition lives with the kernel, not with the dispatch switch: k steps of 128 bytes of every row
+    CM_CHECK((int)((uint32_t)p0.K * (FP8 ? 1 : 2) / 128) >= 6, "launch_mm1pp: needs at least six k steps (the index hand-off at k step 4 and the counted waits at k steps 1 and 2 assume them)");
     auto kern = mm1pp_kernel<FP8>;
     static uint64_t lds_set = 0;
     ensure_dynamic_lds((const void *)kern, PP_LDS, lds_set);
