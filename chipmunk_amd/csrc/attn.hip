@@ -1408,7 +1408,7 @@ extern "C" int chipmunk_dense_colsum_topk_mask_strided(const void *q, const void
     uint16_t *part = (uint16_t *)chipmunk_big_scratch(st, chipmunk_colsum_part_bytes(B, H, Nq, Nk));
     if (!part) return CHIPMUNK_ERR_UNSUPPORTED;
     if (int e = chipmunk_dense64_colsum_launch(p, part, st)) return e;
-    const int nrb = ((Nq + 255) / 256) * 4;
+    const int nrb = ((Nq + 255) / 256) * 2;
     return chipmunk_topk_mask_parts(part, chipmunk_colsum_part_stride(Nk), nrb, p.G, Nq, static_mask, static_stride, static_rows, group_flags, mask, B * H * p.G, Nk,
                                     topk, random_amount, st);
 }

@@ -33,6 +33,7 @@ constexpr int VRING = NSL * TB;           // byte offset of the V ring
 constexpr int LDS_BYTES = 2 * NSL * TB;   // 128 KiB
 constexpr int PSTAGE = 64 * 128;          // MODE 3: a wave's bf16 P tile [64 queries][64 keys] for the column sums on the matrix pipe
 constexpr int LDS_BYTES_CSUM = LDS_BYTES + 4 * PSTAGE;   // 160 KiB: all of a CU's LDS
+constexpr int CS_EXCH_BYTES = 2 * 4 * 64 * 4;           // MODE 3: [tile parity][wave][64 sums] fp32, the waves' exchange area (see prsrc)
 constexpr float SCALE_LOG2E = 0.08838834764f * 1.44269504089f;
 constexpr float MAX_LAG = 4.0f;
 // timing ablations (tools/attn64_ablate.py builds one library per value; results are wrong, only the clock is read):
@@ -373,7 +374,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // CSUM: w = exp2(m c) p_i (the summand exp2(s c + log2 p_i) = P_ij w_i), lpq = log2 p_i, the reduction's last nodes,
     // this lane's byte offset inside a tile's 64 partial sums and the wave's row of the partial-sum buffer
     float wq[2] = {0.f, 0.f}, lpq[2] = {-1.0e30f, -1.0e30f}, c4[2] = {0.f, 0.f}, c5 = 0.f;
-    uint32_t csoff = 0;
+    uint32_t csoff = 0, ex_w = 0, ex_r = 0;
+    int cs_extra = 0;
+    float cs_own = 0.f;      // this wave's sums of the previous tile (its partners' are in the exchange area)
     __amdgpu_buffer_rsrc_t prsrc = krsrc;
     // unit-weight loop: the column sums go over the matrix pipe (below).  pst_w / pst_r: this lane's write / read address for
     // key unit 0 inside the wave's P stage, csf: the fragment reads in flight, csacc / csout: one unit's sums / the tile's
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float csout = 0.f;
     u32x4 cs_ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     if constexpr (CSUM) {
+        static_assert(A64_CSUM_VALU, "the matrix-pipe column-sum probe (A64_CSUM_VALU=0) fills all 160 KiB of LDS with its P stage: no room for the exchange area of the in-workgroup combine; build round 5's tree for it");
         pin(cs_ones);
         const uint32_t pst = lds0 + LDS_BYTES + (uint32_t)w * PSTAGE;
         pst_w = pst + l31 * 128 + ((uint32_t)(hf ^ (l31 & 7)) << 4);
@@ -398,7 +402,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the lane that ends up with key row (kb, u, rr, hf) of the tile: kb = bit 0, u = bit 1, rr = bits 4 3 2 (lsb first)
         const int rr = ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2);
         csoff = 2u * (uint32_t)(32 * (lane & 1) + (rr & 3) + 8 * (2 * ((lane >> 1) & 1) + (rr >> 2)) + 4 * hf);
-        prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 4) + (g * 4 + w)) * p.cs_pstride);
+        // In-workgroup combine (round 6): a 192-row group is three 64-row waves and a workgroup four, so a workgroup's waves belong to
+        // TWO groups -- the first nA = 3 - (4g mod 3) waves to one, the rest to the next.  Each wave drops its tile's 64 sums into a 2 KiB
+        // exchange area behind the rings (one ds_write_b32 per lane and tile), and one tile later -- behind the tile's barrier -- the first
+        // wave of each set adds its partners' (fp32, wave order) and stores ONE bf16 row per set: 2 partial rows per workgroup instead of
+        // 4 (5.3 GB instead of 10.6 at HunyuanVideo size, written here and read by the mask kernel), rounded once per set.
+        const int nA = 3 - (4 * g) % 3;
+        const int lead = w < nA ? 0 : nA, members = w < nA ? nA : 4 - nA;
+        cs_extra = w == lead ? members : 0;       // 0: not a set's first wave; else the waves of the set (1..3)
+        ex_w = lds0 + LDS_BYTES + (uint32_t)w * 256u + (uint32_t)lane * 4u;
+        ex_r = lds0 + LDS_BYTES + (uint32_t)(lead + 1) * 256u + (uint32_t)lane * 4u;
+        prsrc = make_rsrc(p.cs_part + ((int64_t)bh * (p.G * 2) + (g * 2 + (w < nA ? 0 : 1))) * p.cs_pstride);
     }
     // "tile -1": the first pass runs steps 20.. of the softmax pipeline on it -- elements 0..19 as if already exponentiated
 #pragma unroll
@@ -610,18 +624,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr bool UWT = decltype(uwc)::value != 0 && !A64_CSUM_VALU;
             if constexpr (G < (CSUM ? (UWT ? 32 : 17) : 12)) finish_step(ic<52 + G>{}, uwc);
             if constexpr (CSUM && G == (UWT ? 31 : 17)) {
-                // tile t-1's 64 column sums over this wave's 64 queries: one dword per lane into the wave's partial row (a ragged
-                // last tile stores only its own keys, a padding tile nothing)
-                const int tb1 = tile_base(t - 1), dd = (t - 1) * KT - tb1;
-                if (t > 0 && dd < KT) {
-                    const uint32_t off = UWT ? csoff_mx : csoff;
-                    if (dd <= 0 || (int)(off >> 1) >= dd)
-                    {
-                        const uint16_t val = (uint16_t)(pack_bf16x2(UWT ? csout : c5, 0.f) & 0xffffu);
-                        if (p.probe & 16) __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb1 * 2u, 2);
-                        else __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb1 * 2u, 0);
+                // tile t-1's 64 column sums over this wave's 64 queries go to the exchange area (slot parity of the tile); the set's
+                // first wave adds tile t-2's -- its own from last tile, its partners' from the exchange area, complete since this tile's
+                // barrier -- and stores them: one dword per lane into the set's partial row (a ragged last tile stores only its own keys,
+                // a padding tile nothing).  LDS through asm: a read the compiler knows about waits for every DMA in flight.
+                const uint32_t par2 = (uint32_t)(t & 1) * 1024u;            // parity of tile t-2
+                const float mine = UWT ? csout : c5;
+                if (!cs_extra) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(ex_w + (par2 ^ 1024u)), "v"(mine) : "memory");
+                } else {
+                    // (reads, write and wait on ONE path: no edge leaves a read in flight -- tools/audit_async_lds.py checks that)
+                    float x1 = 0.f, x2 = 0.f;
+                    if (cs_extra >= 2) asm volatile("ds_read_b32 %0, %1" : "=v"(x1) : "v"(ex_r + par2) : "memory");
+                    if (cs_extra >= 3) asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(x2) : "v"(ex_r + par2) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(ex_w + (par2 ^ 1024u)), "v"(mine) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(x1), "+v"(x2)::"memory");   // (in order: everything but the write has returned)
+                    const int tb2 = tile_base(t - 2), dd = (t - 2) * KT - tb2;
+                    if (t > 1 && dd < KT) {
+                        const uint32_t off = UWT ? csoff_mx : csoff;
+                        if (dd <= 0 || (int)(off >> 1) >= dd) {
+                            const uint16_t val = (uint16_t)(pack_bf16x2((cs_own + x1) + x2, 0.f) & 0xffffu);
+                            if (p.probe & 16) __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb2 * 2u, 2);
+                            else __builtin_amdgcn_raw_buffer_store_b16(val, prsrc, off, (uint32_t)tb2 * 2u, 0);
+                        }
                     }
                 }
+                cs_own = mine;
             }
             if constexpr (!(A64_ABL & 16) && !GATHER && A64_DMA_POS == 1 && G >= 16 && (G & 1) == 0) {
                 constexpr int PC = (G - 16) >> 1;
@@ -796,6 +824,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P64_END(w, T4 + 1);
+    if constexpr (CSUM) {
+        // the last pass left tile T4-1's sums in cs_own / the exchange area: combine and store them (a padding tile: nothing)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (cs_extra) {
+            float x1 = 0.f, x2 = 0.f;
+            const uint32_t par = (uint32_t)((T4 - 1) & 1) * 1024u;
+            if (cs_extra >= 2) asm volatile("ds_read_b32 %0, %1" : "=v"(x1) : "v"(ex_r + par) : "memory");
+            if (cs_extra >= 3) asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(x2) : "v"(ex_r + par) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x1), "+v"(x2)::"memory");
+            const int tb1 = tile_base(T4 - 1), dd = (T4 - 1) * KT - tb1;
+            const uint32_t off = (unitw && !A64_CSUM_VALU) ? csoff_mx : csoff;
+            if (dd < KT && (dd <= 0 || (int)(off >> 1) >= dd))
+                __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pack_bf16x2((cs_own + x1) + x2, 0.f) & 0xffffu), prsrc, off, (uint32_t)tb1 * 2u, 0);
+        }
+    }
 
     // ---- the accumulators leave the accumulator file: o[(qb*4 + db)*16 + r] = O^T element r of block (qb, db); the row
     //      sums become whole (both lane halves hold the sum over all keys of the query)
@@ -1072,7 +1116,7 @@ template <int MODE>
 int launch64(const AttnParams &p, int64_t grid, hipStream_t stream) {
     auto kern = attn64_kernel<MODE>;
     static uint64_t lds_set = 0;
-    constexpr int LDS = (MODE == 3 && !A64_CSUM_VALU) ? LDS_BYTES_CSUM : LDS_BYTES;
+    constexpr int LDS = (MODE == 3 && !A64_CSUM_VALU) ? LDS_BYTES_CSUM + CS_EXCH_BYTES : MODE == 3 ? LDS_BYTES + CS_EXCH_BYTES : LDS_BYTES;
     ensure_dynamic_lds((const void *)kern, LDS, lds_set);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
     CM_LAUNCH_CHECK();
@@ -1118,15 +1162,18 @@ int chipmunk_dense64_launch(const void *q, const void *k, const void *v, void *o
 // sum_i P_ij w_i with the P the softmax pipeline has in registers anyway and w_i = exp2(m_i c) p_i (m = the reference
 // point).  S^T puts the queries on the lanes, so the sum over a wave's 64 queries is a 5-level reduce-scatter over the 32
 // lanes of a half (cs_pair*: 64 + 63 VALU operations per 64-key tile beside ~2 500 cycles of MFMA) instead of the second
-// pass's 96 MFMAs and 192 exponentials per 192 rows; every wave stores its 64 sums per tile into its own bf16 row (fp32 rows
-// were 21 GB of traffic each way at HunyuanVideo size) and cs_combine_kernel -- or the top-k mask kernel itself, when the
-// caller only wants the mask -- adds the three rows of a group in fp32 (fixed order: the result does not depend on scheduling).
+// pass's 96 MFMAs and 192 exponentials per 192 rows; the waves of a workgroup that share a 192-row group add their 64 sums per tile
+// through LDS and store one bf16 row per set (2 per workgroup; fp32 rows per wave were 21 GB of traffic each way at HunyuanVideo size),
+// and cs_combine_kernel -- or the top-k mask kernel itself, when the caller only wants the mask -- adds the one or two rows of a group
+// in fp32 (fixed order: the result does not depend on scheduling).
 namespace {
 __global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, int pstride, uint16_t *cs, int NRB, int G, int Nq, int Nk, int cs_stride) {
     const int g = blockIdx.y, bh = blockIdx.z;
-    const uint16_t *src = part + ((int64_t)bh * NRB + 3 * g) * pstride;
+    int r0, r1;
+    const int nrows = colsum_part_rows(g, NRB / 2, r0, r1);
+    const uint16_t *src = part + ((int64_t)bh * NRB + r0) * pstride;
+    const int64_t row1 = (int64_t)(r1 - r0) * pstride;     // (only read when nrows == 2)
     uint16_t *dst = cs + ((int64_t)bh * G + g) * cs_stride;
-    const int nrows = min(3, min(NRB - 3 * g, (Nq - 3 * g * 64 + 63) / 64));
     if (((Nk | cs_stride) & 3) == 0) {
         const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
         if (j >= Nk) return;
@@ -1136,8 +1183,8 @@ __global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, i
             acc[0] = __uint_as_float(x[0] << 16), acc[1] = __uint_as_float(x[0] & 0xffff0000u);
             acc[2] = __uint_as_float(x[1] << 16), acc[3] = __uint_as_float(x[1] & 0xffff0000u);
         }
-        for (int r = 1; r < nrows; ++r) {
-            const u32x2 x = *(const u32x2 *)(src + (int64_t)r * pstride + j);
+        if (nrows == 2) {
+            const u32x2 x = *(const u32x2 *)(src + row1 + j);
             acc[0] += __uint_as_float(x[0] << 16), acc[1] += __uint_as_float(x[0] & 0xffff0000u);
             acc[2] += __uint_as_float(x[1] << 16), acc[3] += __uint_as_float(x[1] & 0xffff0000u);
         }
@@ -1147,7 +1194,7 @@ __global__ __launch_bounds__(256) void cs_combine_kernel(const uint16_t *part, i
             const int j = (blockIdx.x * 256 + threadIdx.x) * 4 + e;
             if (j >= Nk) return;
             float acc = bf16_bits_to_f32(src[j]);
-            for (int r = 1; r < nrows; ++r) acc += bf16_bits_to_f32(src[(int64_t)r * pstride + j]);
+            if (nrows == 2) acc += bf16_bits_to_f32(src[row1 + j]);
             dst[j] = f32_to_bf16_bits(acc);
         }
     }
@@ -1167,7 +1214,7 @@ int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream) {
 int chipmunk_colsum_part_stride(int Nk) { return (chipmunk_get_option("attn_cs_probe") & 1) ? Nk : (Nk + 63) & ~63; }
 
 size_t chipmunk_colsum_part_bytes(int B, int H, int Nq, int Nk) {
-    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 4) * (size_t)chipmunk_colsum_part_stride(Nk) * sizeof(uint16_t);
+    return (size_t)B * H * (((Nq + WGROWS - 1) / WGROWS) * 2) * (size_t)chipmunk_colsum_part_stride(Nk) * sizeof(uint16_t);
 }
 
 int chipmunk_dense64_colsum_launch(const AttnParams &p0, uint16_t *part, hipStream_t stream) {
@@ -1181,7 +1228,7 @@ int chipmunk_dense64_colsum_launch(const AttnParams &p0, uint16_t *part, hipStre
     if (int rc = launch64<3>(p, (int64_t)p.B * p.H * p.G, stream)) return rc;
     if (!p.cs) return CHIPMUNK_OK;   // the caller reads the partial rows itself (chipmunk_topk_mask_parts)
     hipLaunchKernelGGL(cs_combine_kernel, dim3((unsigned)((p.Nk + 1023) / 1024), (unsigned)G192, (unsigned)(p.B * p.H)), dim3(256), 0, stream,
-                       part, p.cs_pstride, p.cs, p.G * 4, G192, p.Nq, p.Nk, p.cs_stride);
+                       part, p.cs_pstride, p.cs, p.G * 2, G192, p.Nq, p.Nk, p.cs_stride);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
 }

@@ -46,8 +46,8 @@ int chipmunk_csp64_launch(const AttnParams &p, int inplace, int grid, hipStream_
 // set; `part` = scratch of chipmunk_colsum_part_bytes(...) bytes), followed -- when p.cs is set -- by the combine of the per-wave
 // partial sums into cs; with p.cs == nullptr the partial rows are the result (chipmunk_topk_mask_parts reads them)
 int chipmunk_dense64_colsum_launch(const AttnParams &p, uint16_t *part, hipStream_t stream);
-// indexed_io.hip: the top-k mask straight from the partial rows (row r of the mask = sum of rows 3r .. 3r+2 of `part` in its
-// (batch*head) block of `nrb` rows, rounded to bf16 -- exactly what the combine would have written)
+// indexed_io.hip: the top-k mask straight from the partial rows (row r of the mask = sum of the one or two rows colsum_part_rows names in
+// its (batch*head) block of `nrb` = 2 * workgroups rows, rounded to bf16 -- exactly what the combine would have written)
 int chipmunk_topk_mask_parts(const uint16_t *part, int part_stride, int nrb, int groups_per_bh, int Nq, const void *static_mask, int64_t static_stride,
                              int static_rows, const void *group_flags, void *mask, int rows, int n, int k, double random_amount,
                              hipStream_t stream);
@@ -61,6 +61,17 @@ int chipmunk_colsum64_launch(const AttnParams &p, hipStream_t stream);
 int chipmunk_csp96_launch(const AttnParams &p, int inplace, int grid, hipStream_t stream);
 // attn64.hip: max_j |k_j| per (batch, head) into library scratch (nullptr if switched off / unavailable); see AttnParams::kmax
 const float *chipmunk_knorm_max(const uint16_t *k, const int64_t ks[3], int B, int H, int Nk, hipStream_t stream);
+
+// Partial column-sum rows of attn64.hip MODE 3: per (batch*head) 2 rows per 256-row workgroup -- row 2a = the waves of workgroup a that
+// belong to its FIRST 192-row group, row 2a + 1 = the rest (see the kernel).  Group j starts at wave block 3j = workgroup a, wave w0;
+// it is a's first set when w0 == 0, else its second, and with w0 >= 2 it continues as the first set of workgroup a + 1.
+// Returns the number of rows (1 or 2) and their indices inside the (batch*head) block of 2 * nwg rows.
+__host__ __device__ inline int colsum_part_rows(int j, int nwg, int &r0, int &r1) {
+    const int a = (3 * j) >> 2, w0 = 3 * j - 4 * a;
+    r0 = 2 * a + (w0 ? 1 : 0);
+    r1 = 2 * (a + 1);
+    return (w0 >= 2 && a + 1 < nwg) ? 2 : 1;
+}
 
 struct IndexRow {
     const int32_t *ptr;

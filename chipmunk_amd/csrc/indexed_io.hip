@@ -3,6 +3,7 @@
 // HBM-bound integer/byte kernels: wide coalesced loads, wave64 ballots / popcounts instead of CUB scans,
 // LDS for the per-row bit matrices.  Results are bit-exact against the reference's ordering rules.
 #include "common.h"
+#include "attn_params.h"
 
 namespace {
 
@@ -597,10 +598,13 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
     const int n = p.n;
     const uint16_t *x = nullptr;
     int prow = 1;
+    int64_t row1 = 0;      // PARTS: elements from the group's first partial row to its second
     if constexpr (PARTS) {
         const int bh = row / p.ngroups, g = row - bh * p.ngroups;
-        x = p.parts + ((int64_t)bh * p.nrb + 3 * g) * p.pstride;
-        prow = min(3, min(p.nrb - 3 * g, (p.nq - 3 * g * 64 + 63) / 64));
+        int r0, r1;
+        prow = colsum_part_rows(g, p.nrb / 2, r0, r1);
+        x = p.parts + ((int64_t)bh * p.nrb + r0) * p.pstride;
+        row1 = (int64_t)(r1 - r0) * p.pstride;
     } else {
         x = p.cs + (int64_t)row * p.cs_stride;
     }
@@ -623,15 +627,15 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
                     // wave-uniform base + one shared 32-bit lane offset: the saddr form, no 64-bit address per step
                     const u32x2 v = *(const u32x2 *)((const unsigned char *)(x + 4096 * (j0 + jj)) + lane_off8);
                     v0 = v[0], v1 = v[1];
-                    if constexpr (PARTS) {   // the combine, in its order: (row 0 + row 1) + row 2 in fp32, one rounding to bf16
-                        float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
-                        float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
-                        for (int r = 1; r < prow; ++r) {
-                            const u32x2 y = *(const u32x2 *)((const unsigned char *)(x + (int64_t)r * p.pstride + 4096 * (j0 + jj)) + lane_off8);
+                    if constexpr (PARTS) {   // the combine, in its order: row 0 + row 1 in fp32, one rounding to bf16
+                        if (prow == 2) {
+                            float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
+                            float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
+                            const u32x2 y = *(const u32x2 *)((const unsigned char *)(x + row1 + 4096 * (j0 + jj)) + lane_off8);
                             a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
                             a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
+                            v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
                         }
-                        v0 = pack_bf16x2(a0, a1), v1 = pack_bf16x2(a2, a3);
                     }
                 }
             } else if (c < n) {
@@ -743,8 +747,8 @@ __global__ __launch_bounds__(1024) void topk_mask_kernel(const TopkMaskParams p)
         if constexpr (PARTS) {
             float a0 = __uint_as_float(v0 << 16), a1 = __uint_as_float(v0 & 0xffff0000u);
             float a2 = __uint_as_float(v1 << 16), a3 = __uint_as_float(v1 & 0xffff0000u);
-            for (int r = 1; r < prow; ++r) {
-                const u32x2 y = *(const u32x2 *)(x + (int64_t)r * p.pstride + c0);
+            if (prow == 2) {
+                const u32x2 y = *(const u32x2 *)(x + row1 + c0);
                 a0 += __uint_as_float(y[0] << 16), a1 += __uint_as_float(y[0] & 0xffff0000u);
                 a2 += __uint_as_float(y[1] << 16), a3 += __uint_as_float(y[1] & 0xffff0000u);
             }
