@@ -18,6 +18,7 @@
 //     for near-equal items (see launch_attn); no float atomics, every reduction has a fixed order.
 #include "common.h"
 #include "attn_params.h"
+#include <type_traits>
 
 namespace {
 
@@ -140,7 +141,12 @@ constexpr int BAL_MIN_TILES = 3;    // no part of a cut item is shorter than thi
 constexpr int BAL_MAX_ITEMS = 4096;
 constexpr int BAL_STATE_F4 = 26 * 256;   // float4 per published state: 24 of O, m, l per thread
 
-template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false, bool BAL = false>
+//
+// MIX = a gathered launch whose last `nblocks mod slots` items are ROW-SPLIT (round 6): item i >= p.split_full runs as three workgroups of
+// 64 query rows -- four waves x ONE 16-row query block (QB = 1) instead of three -- so that the poorly filled last round is made of
+// workgroups with a third of the softmax / MFMA work per key tile.  Rows are independent: no partial state, no merge, same bits as the
+// unsplit item.  Both bodies live in the one kernel (the thirds must start as slots free up, not behind a launch boundary).
+template <bool GATHER, bool INPLACE, bool WRITE_L, bool CSONLY = false, bool BAL = false, bool MIX = false>
 __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KEYOFF = (CSONLY ? NST : NST + NSTV) * TILE_BYTES;  // the column-sum pass has no V ring
@@ -228,14 +234,20 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int tid = tid_o, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
+    // one item (or BAL segment) with QB 16-row query blocks per wave: 3 = a whole 192-row group, 1 = a 64-row third of it (MIX)
+    auto item_body = [&](auto qbc, const int third) __attribute__((always_inline)) {
+    constexpr int QB = decltype(qbc)::value;
+    constexpr int QWB = 16 * QB;     // query rows per wave
+    static_assert(QB == 3 || (QB == 1 && GATHER && !CSONLY && !BAL && !WRITE_L), "thirds exist for the gathered forms only");
     const bool bal_publish = BAL && bal_item == bal_jr;                    // (only reached with cr > 0)
     const bool bal_consume = BAL && bal_item == bal_jl && bal_cl > 0;
 
     int wid0 = p.xcd_chunks ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     if constexpr (BAL) wid0 = bal_item;
+    if constexpr (MIX) wid0 = third < 0 ? wid0 : p.split_full + (wid0 - p.split_full) / 3;
     // sp / nsp: this workgroup's slice of the item's key tiles; slot0: scratch slot of the item's slice 0; tix: its ticket
     int sp = 0, nsp = 1, slot0 = 0, tix = 0, wid = wid0;
-    if (BAL) {
+    if (BAL || MIX) {
     } else if (!CSONLY && p.plan) {
         const u32x2 entry = *(const u32x2 *)(p.plan + 2 * wid0);   // (one round trip, not two)
         wid = (int)entry[0];
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const int32_t *idx = irow.ptr;
     const uint16_t *kbase = p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t *vbase = p.v + b * p.vs[0] + h * p.vs[1];
-    const int row0 = g * QG + w * QW;
+    const int row0 = g * QG + (QB == 3 ? w * QW : third * 64 + w * QWB);
     // wave 0 streams 64 indices starting at tile T into key slot T % KRING (only the first 32 are tile T's)
     auto issue_keys = [&](int T) {
         if constexpr (GATHER) {
@@ -285,9 +297,9 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     const uint32_t kstride_b = (uint32_t)p.ks[2] * 2u, vstride_b = (uint32_t)p.vs[2] * 2u;  // row strides in bytes
 
     // ---- Q^T fragments (B operand): lane = query column li, k = lg*8..lg*8+7 of each 32-wide d step
-    bf16x8 qf[3][4];
+    bf16x8 qf[QB][4];
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qrow = row0 + qb * 16 + li;
         const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qrow * p.qs[2];
 #pragma unroll
@@ -369,13 +381,14 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     };
 
 
-    f32x4 o[3][8];
+    f32x4 o[QB][8];
+    float m[QB], lsum[QB];
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb)
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = -INFINITY, lsum[qb] = 0.f;
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float lsum[3] = {0.f, 0.f, 0.f};
+    }
     const __amdgpu_buffer_rsrc_t bal_rsrc = make_rsrc(BAL ? (const void *)p.ws : (const void *)p.q);
     constexpr uint32_t BAL_STATE_BYTES = BAL_STATE_F4 * 16;
 
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             const uint32_t sb = (uint32_t)bal_L * BAL_STATE_BYTES + (uint32_t)tid * 16u;
             if (!(p.probe & 16))   // (timing probes: 16 = no state traffic, 32 = no flag wait either; results are then wrong)
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb)
+            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int db = 0; db < 8; ++db)
                     o[qb][db] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bal_rsrc, sb + (qb * 8 + db) * 4096, 0, 16));
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             const f32x4 ls = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bal_rsrc, sb + 25 * 4096, 0, 16));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) m[qb] = ms[qb], lsum[qb] = ls[qb];
+            for (int qb = 0; qb < QB; ++qb) m[qb] = ms[qb], lsum[qb] = ls[qb];
         }
     }
     // accumulate forms of an unsplit item with work to do: the epilogue's base rows are fetched ahead of the drain tile
@@ -499,10 +512,10 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     // the loads out on the spot)
     const bool early_base = INPLACE && !BAL && nsp == 1 && tend > tbeg;
     const bool base_before_drain = early_base;
-    u32x4 base[INPLACE ? QW * 256 / 1024 : 1];
+    u32x4 base[INPLACE ? QWB * 256 / 1024 : 1];
     auto fetch_base = [&]() {
 #pragma unroll
-        for (int i = 0; i < QW * 256 / 1024; ++i) {
+        for (int i = 0; i < QWB * 256 / 1024; ++i) {
             const int qrow = row0 + i * 4 + (lane >> 4);
             base[i] = (u32x4){0u, 0u, 0u, 0u};
             if (qrow < p.Nq) base[i] = *(const u32x4 *)(p.o_in + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2] + (lane & 15) * 8);
@@ -522,11 +535,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         // the relative precision of the bf16 P and of the fp32 sums is unchanged, and the O / l rescale (72 VALU issues) runs
         // only when some query column of the wave outgrows the lag -- VALU issue slots, not MFMA time, bound this loop.
         constexpr float MAX_LAG = 4.0f;
-        bf16x8 pq[3];   // P^T of the tile whose PV is pending
+        bf16x8 pq[QB];   // P^T of the tile whose PV is pending
+        f32x4 s[QB][2];
+        float alpha[QB], nmsc[QB];            // nmsc = -m*c, kept beside m (recomputed only when the reference point moves)
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) pq[qb] = (bf16x8){};
-        f32x4 s[3][2];
-        float alpha[3] = {1.f, 1.f, 1.f};
+        for (int qb = 0; qb < QB; ++qb) pq[qb] = (bf16x8){}, alpha[qb] = 1.f, nmsc[qb] = 0.f;
         // keys of the tile whose data goes out NEXT, read from the key ring one iteration ahead (a read at the point of
         // use costs two exposed LDS round trips per tile: ds_read -> lgkmcnt(0) -> address -> DMA, twice)
         int knext[2] = {0, 0};
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 const int kt = i >> 2, ks = i & 3;
                 // the first k step starts from the inline constant 0 (an explicit zero fill costs 24 VALU issues per tile)
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb)
+                for (int qb = 0; qb < QB; ++qb)
                     s[qb][kt] = mfma16(kr[i % FR], qf[qb][ks], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : s[qb][kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                     for (int r = 0; r < 4; ++r) {
                         const bool dead = t * KVT + kt * 16 + lg * 4 + r >= valid;
 #pragma unroll
-                        for (int qb = 0; qb < 3; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+                        for (int qb = 0; qb < QB; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
                     }
             }
             PROF_MARK(2);
@@ -597,7 +610,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         };
         // the steady loop's forms: all three query blocks in ONE statement each (hipcc pads every asm statement that writes a
         // VGPR with an s_nop and copies operands around single-instruction helpers: 24 statements -> 2 per tile)
-        auto tile_max_x3 = [&](float (&mx)[3]) {
+        auto tile_max_x3 = [&](float (&mx)[QB]) {
+            if constexpr (QB != 3) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) mx[qb] = tile_max(qb);
+            } else
             asm volatile(
                 "v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %11, %12, %13\n\tv_max3_f32 %2, %19, %20, %21\n\t"
                 "v_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %14, %15\n\tv_max3_f32 %2, %2, %22, %23\n\t"
@@ -608,8 +625,12 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                   "v"(s[1][0][0]), "v"(s[1][0][1]), "v"(s[1][0][2]), "v"(s[1][0][3]), "v"(s[1][1][0]), "v"(s[1][1][1]), "v"(s[1][1][2]), "v"(s[1][1][3]),
                   "v"(s[2][0][0]), "v"(s[2][0][1]), "v"(s[2][0][2]), "v"(s[2][0][3]), "v"(s[2][1][0]), "v"(s[2][1][1]), "v"(s[2][1][2]), "v"(s[2][1][3]));
         };
-        auto max_rows_x3 = [&](float (&mx)[3]) {   // max over the four 16-lane rows of the wave, three values at once
+        auto max_rows_x3 = [&](float (&mx)[QB]) {   // max over the four 16-lane rows of the wave, three values at once
             float t0, t1, t2;
+            if constexpr (QB != 3) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) mx[qb] = max_rows(mx[qb]);
+            } else
             asm volatile(
                 "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\ts_nop 1\n\t"
                 "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5\n\ts_nop 0\n\t"
@@ -619,7 +640,6 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
                 : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2));
         };
-        float nmsc[3] = {0.f, 0.f, 0.f};            // -m*c, kept beside m (recomputed only when the reference point moves)
         auto exp_block = [&](int qb, float nm) {    // p = exp2(s*c - m*c), in place
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -651,8 +671,14 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 const bf16x8 vf = __builtin_bit_cast(
                     bf16x8, (__attribute__((ext_vector_type(8))) short){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vf, pq[qb], o[qb][db]);
+                for (int qb = 0; qb < QB; ++qb) o[qb][db] = mfma16(vf, pq[qb], o[qb][db]);
             }
+        };
+        auto within_lag = [&](const float (&mx)[QB], float lag) {   // per lane: every query block's tile maximum within `lag` of its reference point
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) ok = ok && mx[qb] <= m[qb] + lag;
+            return ok;
         };
         if (tend > tbeg) {
             // ---- first tile: the reference point is its own maximum (exact), nothing to rescale
@@ -660,13 +686,13 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             qk_tile(tbeg);
             if (BAL && bal_consume) {
                 // a continued item: the reference point is the published one, moved (with the rescale) only if this tile outgrows the lag
-                float mx[3];
+                float mx[QB];
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) mx[qb] = max_rows(tile_max(qb));
+                for (int qb = 0; qb < QB; ++qb) mx[qb] = max_rows(tile_max(qb));
                 constexpr float LAG_RAW0 = MAX_LAG / SCALE_LOG2E;
-                if (!__all(mx[0] <= m[0] + LAG_RAW0 && mx[1] <= m[1] + LAG_RAW0 && mx[2] <= m[2] + LAG_RAW0)) {
+                if (!__all(within_lag(mx, LAG_RAW0))) {
 #pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) {
+                    for (int qb = 0; qb < QB; ++qb) {
                         const float m_new = max2(m[qb], mx[qb]);
                         const float a = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
                         lsum[qb] *= a;
@@ -677,7 +703,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                 }
             }
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 if (!(BAL && bal_consume)) m[qb] = max_rows(tile_max(qb));
                 nmsc[qb] = -m[qb] * SCALE_LOG2E;
                 exp_block(qb, nmsc[qb]);
@@ -707,23 +733,23 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                     };
                     bf16x8 vr[3];
                     vr[0] = load_v(0), vr[1] = load_v(1);
-                    float mx[3];
+                    float mx[QB];
                     __builtin_amdgcn_sched_barrier(0);
                     // chunks 0, 1: maxima; then the (rare) reference update in its own block; chunks 2..7: exp2, row sums
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         vr[(db + 2) % 3] = load_v(db + 2);
 #pragma unroll
-                        for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
+                        for (int qb = 0; qb < QB; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
                         if (db == 0) tile_max_x3(mx);
                         else max_rows_x3(mx);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     constexpr float LAG_RAW = MAX_LAG / SCALE_LOG2E;   // the lag in units of the raw scores
-                    if (!__all(mx[0] <= m[0] + LAG_RAW && mx[1] <= m[1] + LAG_RAW && mx[2] <= m[2] + LAG_RAW)) {
+                    if (!__all(within_lag(mx, LAG_RAW))) {
                         moved = true;
 #pragma unroll
-                        for (int qb = 0; qb < 3; ++qb) {
+                        for (int qb = 0; qb < QB; ++qb) {
                             const float m_new = max2(m[qb], mx[qb]);
                             alpha[qb] = __builtin_amdgcn_exp2f((m[qb] - m_new) * SCALE_LOG2E);
                             lsum[qb] *= alpha[qb];   // (o is rescaled once the pending PV has been accumulated)
@@ -736,29 +762,33 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
                     for (int db = 2; db < 8; ++db) {
                         if (db + 2 < 8) vr[(db + 2) % 3] = load_v(db + 2);
 #pragma unroll
-                        for (int qb = 0; qb < 3; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
+                        for (int qb = 0; qb < QB; ++qb) o[qb][db] = mfma16(vr[db % 3], pq[qb], o[qb][db]);
                         if (db <= 4) {              // exp2 of one query block per chunk
                             const int qb = db - 2;
-                            exp_block(qb, nmsc[qb]);
-                            pin(s[qb][0]);
-                            pin(s[qb][1]);
+                            if (qb < QB) {
+                                exp_block(qb, nmsc[qb]);
+                                pin(s[qb][0]);
+                                pin(s[qb][1]);
+                            }
                         } else {                    // row sums
                             const int qb = db - 5;
-                            row_sum(qb);
-                            pin(lsum[qb]);
+                            if (qb < QB) {
+                                row_sum(qb);
+                                pin(lsum[qb]);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // P^T of tile t as bf16: only once the last MFMA on tile t-1's P has been issued (a second set of P
                     // registers would push the kernel over 256 VGPRs)
 #pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) pq[qb] = to_bf16(qb);
+                    for (int qb = 0; qb < QB; ++qb) pq[qb] = to_bf16(qb);
                 }
                 PROF_MARK(3);
                 // rescale AFTER the pending PV has been accumulated: O_t = alpha_t (O_{t-1} + P_{t-1} V_{t-1}) + P_t V_t
                 if (moved) {
 #pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) {
+                    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
                         for (int db = 0; db < 8; ++db) o[qb][db] *= alpha[qb];
                     }
@@ -776,6 +806,7 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     PROF_ABS(3);
     TL_MARK(4 + 4 * tl_seg);
 
+    if constexpr (QB == 3) {
     if (nsp > 1) {
         // ---- key-split item: publish this slice's (o, m, l) lane-linear (26 float4 per lane), take a ticket; the last
         //      arriver folds the other slices in (the lane layout is the same in every slice, so the merge is the
@@ -830,7 +861,11 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
             }
         }
     }
+    }
+    bool published = false;
+    if constexpr (QB == 3) {
     if (BAL && bal_publish) {
+        published = true;
         // ---- the head of a cut item: the state goes to the right neighbour (slot L + 1), write-through; no epilogue
         const uint32_t sb = (uint32_t)(bal_L + 1) * BAL_STATE_BYTES + (uint32_t)tid * 16u;
         if (!(p.probe & 16))
@@ -844,21 +879,23 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // every wave's stores have been acknowledged (and everybody is done with the rings and the key ring)
         if (tid == 0 && !(p.probe & 32)) __hip_atomic_store(p.tickets + BAL_FLAG + bal_L + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    }
+    }
+    if (!published) {
     // ---- epilogue: O = O^T / l.  A lane holds 4 consecutive d (8 bytes) of one query row per (qb, db): stored as they stand that is
     //      24 eight-byte accesses per lane, each instruction touching 16 rows x 32 bytes (and as many loads for the accumulate forms):
     //      the store tail was 15.8 k of a FLUX item's 114 k cycles (tools/attn_prof.py).  The wave's 48 x 128 bf16 results go through
     //      its own 12 KiB of the (now idle) K/V rings instead -- 8-byte writes, chunk index XOR row so that the 16 lanes of a write land on
     //      16 different chunks -- and leave as 12 whole-row 16-byte accesses per lane (4 rows = 1 KiB per instruction); the accumulation
     //      base is fetched in that same layout BEFORE the drain tile when this workgroup is sure to run the epilogue.
-    constexpr int EP_I = QW * 256 / 1024;   // 16-byte pieces per lane: 12
-    unsigned char *stage = smem + w * (QW * 256);
+    constexpr int EP_I = QWB * 256 / 1024;   // 16-byte pieces per lane: 12 (a third: 4)
+    unsigned char *stage = smem + w * (QWB * 256);
     const int er0 = lane >> 4, ech = lane & 15;
     auto ep_row = [&](int i) { return i * 4 + er0; };   // wave-local row of piece i
     const int64_t obase = b * p.os[0] + h * p.os[1];
     __syncthreads();   // every wave is done with the rings
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const float l = sum_across_rows(lsum[qb]);
         const float inv = (l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f) * (INPLACE ? p.o_scale : 1.f);   // o_scale = +-1: exact
         const int r = qb * 16 + li;
@@ -897,6 +934,15 @@ __global__ __launch_bounds__(256, CSONLY ? 4 : 2) void attn_kernel(const AttnPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the mark is taken once the stores have left
 #endif
     PROF_ABS(4);
+    }
+    };   // item_body
+    if constexpr (MIX) {
+        // the last items of the launch as thirds: workgroup split_full + 3 k + j = rows 64 j .. 64 j + 63 of item split_full + k
+        const int k3 = (int)blockIdx.x - p.split_full;
+        if (k3 >= 0) item_body(std::integral_constant<int, 1>{}, k3 % 3);
+        else item_body(std::integral_constant<int, 3>{}, -1);
+    } else {
+        item_body(std::integral_constant<int, 3>{}, -1);
     }
     TL_MARK(5 + 4 * tl_seg);
     ++tl_seg;
@@ -1104,6 +1150,25 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
                 CM_LAUNCH_CHECK();
                 return CHIPMUNK_OK;
             }
+        }
+    }
+    // Row-split tail (MIX, see attn_kernel): the last `nblocks mod slots` items of a gathered launch of at least one full round run as
+    // three 64-row workgroups each, when that many thirds fit the slots.  Option attn_row_split: 0 = by shape, 1 = always (the last
+    // min(nblocks, slots / 3) items; tests), 2 = never.
+    if constexpr (GATHER && !CSONLY && !WRITE_L) {
+        const int orow = chipmunk_get_option("attn_row_split");
+        const int64_t slots = wg_per_cu * (int64_t)device_cu_count();
+        int64_t rem = nblocks > slots ? nblocks % slots : 0;
+        if (orow == 1) rem = nblocks < slots / 3 ? nblocks : slots / 3;
+        if (!pp.plan && !pp.xcd_chunks && orow != 2 && rem > 0 && rem * 3 <= slots) {
+            auto km = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY, false, true>;
+            static uint64_t lds_set_m = 0;
+            ensure_dynamic_lds((const void *)km, ATTN_LDS_BYTES, lds_set_m);
+            pp.split_full = (int)(nblocks - rem);
+            pp.nsplit = 0;
+            hipLaunchKernelGGL(km, dim3((unsigned)(nblocks - rem + 3 * rem)), dim3(256), ATTN_LDS_BYTES, stream, pp);
+            CM_LAUNCH_CHECK();
+            return CHIPMUNK_OK;
         }
     }
     // Key-split tail.  Workgroups are dispatched in block order as the 2-per-CU slots free up; with near-equal items
