@@ -30,7 +30,7 @@ WORKLOADS = {
     "hunyuan_c3": (["--steps", "2", "--warmup", "3", "--no-legs", "--dense-steps", "0", "--no-cpu-baseline", "--no-step-caching"], OPS,
                    "bench.py's own launches (hunyuan_c3: 24 heads x 119 056 tokens, ragged module-generated key counts)"),
     "flux_c2": (["--workload", "flux_c2", "--steps", "4", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline"],
-                {"mm1+scatter_add": ["mm1_kernel<128, 64, 2, 2, false"], "mm2": ["mm2_kernel"], "csp_attn": ["attn_kernel<true, true, false, false>"],
+                {"mm1+scatter_add": ["mm1_kernel<128, 64, 2, 2, false"], "mm2": ["mm2_kernel"], "csp_attn": ["attn_kernel<true, true, false, false"],
                  "topk_delta_indices": ["topk_indices_kernel"], "block_mean": ["block_mean_kernel"]},
                 "bench.py's own launches (flux_c2: 24 heads x 4 352 tokens, 672 kept keys; MLP 34 / 30 groups, module-generated index lists)"),
     "wan_c5": (["--workload", "wan_c5", "--steps", "2", "--warmup", "12", "--dense-steps", "0", "--no-cpu-baseline"],
