@@ -123,9 +123,13 @@ def build_wan(dev, args, timer):
     def tokens_first(o):
         return o[0].permute(1, 0, 2).reshape(o.shape[2], H * D)
 
-    def block(blk, x, inv, li, how):
+    def block(blk, x, inv, li, how, xm=None, nxt=None):
+        """xm: LayerNorm + modulate of x when the previous block's closing pass already produced it; nxt: the (shift, scale) of the block that
+        follows (its opening LayerNorm + modulate then rides this block's closing gated residual: one row-wise pass instead of an addcmul and a
+        separate norm pass).  Returns (x, xm for the next block | None)."""
         m = blk["mod"]
-        xm = ln_mod(x, m[0], m[1])
+        if xm is None:
+            xm = ln_mod(x, m[0], m[1])
         ops_pkg.qkv_split_norm(torch.addmm(blk["qkv"].bias, xm, blk["qkv"].weight.t()), None, None, H, 1e-6)   # cost; see the docstring
         q, k, v = qkv[inv][li % NSETS]
         if how == "sparse":
@@ -161,7 +165,9 @@ def build_wan(dev, args, timer):
             blk["mlp"].storage.complete_cur_layer()
         else:
             y = bench.dense_mlp(xm, blk["fc1_dense"], blk["fc2"])
-        return torch.addcmul(x, m[5], y)
+        if fused_rowwise and nxt is not None:
+            return ops_pkg.residual_ln_modulate(x, y, m[5], nxt[0], nxt[1], 1e-6)
+        return torch.addcmul(x, m[5], y), None
 
     stall_probe = [] if os.environ.get("WAN_STALL_PROBE") == "1" else None
 
@@ -175,7 +181,7 @@ def build_wan(dev, args, timer):
                     kinds.append("skipped")
                     continue
                 kinds.append("full" if counter.should_do_full_attn_step() else "sparse")
-                x = xs[inv][i % NX]
+                x, xm = xs[inv][i % NX], None
                 for li, blk in enumerate(layers):
                     nxt = layers[(li + 1) % L]
                     if inference_step > 0 or li > 0 or inv > 0:
@@ -188,7 +194,7 @@ def build_wan(dev, args, timer):
                         else:
                             blk["attn"].storage.load_async_wait()
                     nxt["attn"].storage.load_async()
-                    x = block(blk, x, inv, li, "sparse")
+                    x, xm = block(blk, x, inv, li, "sparse", xm, (nxt["mod"][0], nxt["mod"][1]) if li + 1 < L else None)
                 step_cache.store(x)
 
     def dense_step(i, how="sdpa"):
@@ -198,9 +204,9 @@ def build_wan(dev, args, timer):
                     d = lin(HID, FFN)
                     blk["fc1_dense"] = d
             for inv in range(n_inv):
-                x = xs[inv][i % NX]
+                x, xm = xs[inv][i % NX], None
                 for li, blk in enumerate(layers):
-                    x = block(blk, x, inv, li, how)
+                    x, xm = block(blk, x, inv, li, how, xm, (layers[li + 1]["mod"][0], layers[li + 1]["mod"][1]) if li + 1 < L else None)
 
     def offload_bytes():
         mods = [b["attn"] for b in layers if b["attn"].storage.out_cache.cpu_buf[0] is not None]
