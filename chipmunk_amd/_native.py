@@ -17,6 +17,7 @@ SYMBOLS = [
     "chipmunk_csp_mlp_mm1", "chipmunk_csp_mlp_mm1_scatter", "chipmunk_csp_mlp_mm1_fp8", "chipmunk_csp_mlp_mm2_and_scatter_add", "chipmunk_csp_scatter_add", "chipmunk_csp_mlp_mm2",
     "chipmunk_topk_indices", "chipmunk_topk_delta_indices", "chipmunk_topk_mask", "chipmunk_mask_to_indices", "chipmunk_mask_to_sorted_indices", "chipmunk_packed_mask_to_indices", "chipmunk_copy_indices",
     "chipmunk_bitpack", "chipmunk_bitunpack", "chipmunk_transpose16", "chipmunk_block_mean", "chipmunk_quantize_fp8", "chipmunk_gather_rows", "chipmunk_qkv_split_norm", "chipmunk_dense_colsum_topk_mask", "chipmunk_dense_attn_strided", "chipmunk_csp_attn_out_ragged", "chipmunk_compact_indices", "chipmunk_residual_ln_modulate", "chipmunk_dense_colsum_attn_strided", "chipmunk_dense_colsum_topk_mask_strided", "chipmunk_release_scratch", "chipmunk_big_scratch_fallbacks",
+    "chipmunk_host_alloc", "chipmunk_host_free", "chipmunk_copy_d2h_async", "chipmunk_copy_h2d_async", "chipmunk_host_bytes",
 ]
 
 _lib = None
@@ -58,3 +59,55 @@ def manual_seed(seed: int) -> None:
     """Restart the random-key sequence of topk_indices / topk_mask (`random_amount` > 0): same seed + same launch order
     = same random columns.  Without a call the sequence starts from a fixed default seed."""
     check(lib().chipmunk_set_random_seed(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)), "chipmunk_set_random_seed")
+
+
+class HostBuffer:
+    """Page-locked host memory from the library's pool (``chipmunk_host_alloc`` = hipHostMalloc): the pinned side of the cache offload
+    (reference ``util/storage/offloaded_tensor.py:42-44,71`` keeps ``torch.empty(..., pin_memory=True)`` tensors).  Exposes the few
+    tensor-like accessors the storage code and the reports use."""
+
+    def __init__(self, numel: int, dtype) -> None:
+        import torch
+        self.dtype = dtype
+        self._numel = int(numel)
+        self._itemsize = torch.empty(0, dtype=dtype).element_size()
+        self.nbytes = self._numel * self._itemsize
+        p = ctypes.c_void_p()
+        check(lib().chipmunk_host_alloc(ctypes.c_size_t(max(self.nbytes, 1)), ctypes.byref(p)), "chipmunk_host_alloc")
+        self.ptr = p.value
+
+    def numel(self) -> int:
+        return self._numel
+
+    def element_size(self) -> int:
+        return self._itemsize
+
+    def is_pinned(self) -> bool:
+        return True
+
+    def free(self) -> None:
+        if getattr(self, "ptr", None):
+            lib().chipmunk_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def copy_d2h_async(host_ptr: int, dev_ptr: int, nbytes: int, stream: int) -> None:
+    check(lib().chipmunk_copy_d2h_async(ctypes.c_void_p(host_ptr), ctypes.c_void_p(dev_ptr), ctypes.c_size_t(nbytes), ctypes.c_void_p(stream)),
+          "chipmunk_copy_d2h_async")
+
+
+def copy_h2d_async(dev_ptr: int, host_ptr: int, nbytes: int, stream: int) -> None:
+    check(lib().chipmunk_copy_h2d_async(ctypes.c_void_p(dev_ptr), ctypes.c_void_p(host_ptr), ctypes.c_size_t(nbytes), ctypes.c_void_p(stream)),
+          "chipmunk_copy_h2d_async")
+
+
+def host_bytes() -> int:
+    f = lib().chipmunk_host_bytes
+    f.restype = ctypes.c_size_t
+    return int(f())

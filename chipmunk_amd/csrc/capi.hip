@@ -148,6 +148,59 @@ extern "C" int chipmunk_big_scratch_fallbacks(void) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     return g_big_fallbacks;
 }
+// ---- pinned host offload pool (include/chipmunk_hip.h): hipHostMalloc + hipMemcpyAsync on the caller's side stream ----
+namespace {
+std::mutex g_host_mu;
+std::map<void *, size_t> g_host_allocs;
+size_t g_host_total = 0;
+}
+extern "C" int chipmunk_host_alloc(size_t bytes, void **host_ptr) {
+    CM_CHECK(host_ptr != nullptr && bytes > 0, "chipmunk_host_alloc: null result pointer or zero bytes");
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess || !p) {
+        chipmunk_set_error("chipmunk_host_alloc: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return CHIPMUNK_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    g_host_allocs[p] = bytes;
+    g_host_total += bytes;
+    *host_ptr = p;
+    return CHIPMUNK_OK;
+}
+extern "C" int chipmunk_host_free(void *host_ptr) {
+    if (!host_ptr) return CHIPMUNK_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mu);
+        auto it = g_host_allocs.find(host_ptr);
+        CM_CHECK(it != g_host_allocs.end(), "chipmunk_host_free: %p was not allocated by chipmunk_host_alloc", host_ptr);
+        g_host_total -= it->second;
+        g_host_allocs.erase(it);
+    }
+    (void)hipHostFree(host_ptr);
+    return CHIPMUNK_OK;
+}
+extern "C" size_t chipmunk_host_bytes(void) {
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    return g_host_total;
+}
+static int copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream, const char *what) {
+    CM_CHECK(dst && src, "%s: null pointer", what);
+    if (bytes == 0) return CHIPMUNK_OK;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        chipmunk_set_error("%s: hipMemcpyAsync of %zu bytes failed: %s", what, bytes, hipGetErrorString(e));
+        return CHIPMUNK_ERR_LAUNCH;
+    }
+    return CHIPMUNK_OK;
+}
+extern "C" int chipmunk_copy_d2h_async(void *host_dst, const void *dev_src, size_t bytes, void *stream) {
+    return copy_async(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream, "chipmunk_copy_d2h_async");
+}
+extern "C" int chipmunk_copy_h2d_async(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
+    return copy_async(dev_dst, host_src, bytes, hipMemcpyHostToDevice, stream, "chipmunk_copy_h2d_async");
+}
+
 extern "C" int chipmunk_release_scratch(void) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     (void)hipDeviceSynchronize();

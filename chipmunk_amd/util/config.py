@@ -77,6 +77,9 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
     # flag is on stay resident on the device as long as `hbm_budget_gb` is not exceeded.
     "offloading.keep_resident_if_fits": False,
     "offloading.hbm_budget_gb": 200.0,
+    # pinned host buffers from the library's own pool (chipmunk_host_alloc = hipHostMalloc) and hipMemcpyAsync through the C ABI
+    # (chipmunk_copy_d2h_async / _h2d_async) instead of torch's pinned tensors + copy_(non_blocking=True)
+    "offloading.native_host_pool": True,
     # use the fused packed-bits -> indices kernel instead of bitunpack + mask_to_indices
     "attn.fused_packed_mask_to_indices": True,
     # with the fused path: emit the kept keys in ascending order (same set; sequential DRAM pages for the gather)
@@ -114,6 +117,7 @@ AMD_EXTRA_KEYS: Dict[str, Any] = {
 }
 BASE_CONFIG["offloading"]["keep_resident_if_fits"] = AMD_EXTRA_KEYS["offloading.keep_resident_if_fits"]
 BASE_CONFIG["offloading"]["hbm_budget_gb"] = AMD_EXTRA_KEYS["offloading.hbm_budget_gb"]
+BASE_CONFIG["offloading"]["native_host_pool"] = AMD_EXTRA_KEYS["offloading.native_host_pool"]
 BASE_CONFIG["attn"]["fused_packed_mask_to_indices"] = AMD_EXTRA_KEYS["attn.fused_packed_mask_to_indices"]
 BASE_CONFIG["attn"]["sorted_indices"] = AMD_EXTRA_KEYS["attn.sorted_indices"]
 BASE_CONFIG["mlp"]["fused_topk_delta"] = AMD_EXTRA_KEYS["mlp.fused_topk_delta"]

@@ -3,9 +3,10 @@
 
 MI355X-first differences from the reference, none of which change results:
 
-* the pinned host buffer (``hipHostMalloc`` through torch's pinned allocator) is sized to the tensor actually stored
-  instead of a fixed 1.23 GB / 410 MB per layer per name (reference ``:42-44,71``), and is reused across steps;
-* copies are ``hipMemcpyAsync`` (``copy_(non_blocking=True)``) on two process-wide side streams created lazily on first
+* the pinned host buffer comes from the library's own pool (``chipmunk_host_alloc`` = ``hipHostMalloc``, include/chipmunk_hip.h; round 6 --
+  torch's pinned allocator before, and still with ``offloading.native_host_pool`` off), sized to the tensor actually stored instead of a
+  fixed 1.23 GB / 410 MB per layer per name (reference ``:42-44,71``), and is reused across steps;
+* copies are ``hipMemcpyAsync`` (``chipmunk_copy_d2h_async`` / ``_h2d_async``) on two process-wide side streams created lazily on first
   use -- importing the package never touches the device (the reference creates CUDA streams at import, ``:12-13``);
 * residency policy: with ``offloading.keep_resident_if_fits`` a tensor whose offload flag is set stays in HBM while the
   running total is under ``offloading.hbm_budget_gb`` (288 GB holds HunyuanVideo's 57 GB of per-layer caches);
@@ -82,6 +83,13 @@ def reserve_kept_offloaded(nbytes: int) -> bool:
 def release_kept_offloaded(nbytes: int) -> None:
     global _kept_offloaded_bytes
     _kept_offloaded_bytes = max(0, _kept_offloaded_bytes - nbytes)
+
+
+def _native_pool(t: torch.Tensor) -> bool:
+    """Device tensors go through the library's own pinned pool (``chipmunk_host_alloc`` = hipHostMalloc, ``chipmunk_copy_*_async`` =
+    hipMemcpyAsync on the side streams; ``offloading.native_host_pool``, on by default); CPU tensors (the reference's op sequence in the
+    CPU tests) and a switched-off key keep torch's pinned tensors."""
+    return bool(t.is_cuda and amd_key("offloading", "native_host_pool"))
 
 
 def _side_stream(kind: str) -> "torch.cuda.Stream":
@@ -174,15 +182,26 @@ class MaybeOffloadedTensor:
             gpu_tensor = gpu_tensor.contiguous()
         self.real_stride[key] = tuple(gpu_tensor.stride())
         buf = self.cpu_buf[key]
-        if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype:
-            buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
+        native = _native_pool(gpu_tensor)
+        if buf is None or buf.numel() < gpu_tensor.numel() or buf.dtype != gpu_tensor.dtype or isinstance(buf, torch.Tensor) == native:
+            if native:      # the library's pool: hipHostMalloc through the C ABI (chipmunk_host_alloc)
+                from ... import _native as _n
+                buf = _n.HostBuffer(gpu_tensor.numel(), gpu_tensor.dtype)
+            else:
+                buf = torch.empty(gpu_tensor.numel(), dtype=gpu_tensor.dtype, device="cpu", pin_memory=True)
             self.cpu_buf[key] = buf
         side = offload_stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            # same strides on both sides: one hipMemcpyAsync of the storage, whatever the dimension order
-            buf[: gpu_tensor.numel()].as_strided(gpu_tensor.shape, self.real_stride[key]).copy_(gpu_tensor, non_blocking=True)
+        if native:
+            # the tensor's storage as it lies (a dense permuted layout included): one hipMemcpyAsync on the offload stream
+            from ... import _native as _n
+            _n.copy_d2h_async(buf.ptr, gpu_tensor.data_ptr(), gpu_tensor.numel() * gpu_tensor.element_size(), side.cuda_stream)
             gpu_tensor.record_stream(side)
+        else:
+            with torch.cuda.stream(side):
+                # same strides on both sides: one hipMemcpyAsync of the storage, whatever the dimension order
+                buf[: gpu_tensor.numel()].as_strided(gpu_tensor.shape, self.real_stride[key]).copy_(gpu_tensor, non_blocking=True)
+                gpu_tensor.record_stream(side)
         ev = _last_offload_event.get(gpu_tensor.device.index)
         if ev is None:
             ev = _last_offload_event[gpu_tensor.device.index] = torch.cuda.Event()
@@ -249,8 +268,14 @@ class MaybeOffloadedTensor:
         ev = _last_offload_event.get(slot.device.index)
         if ev is not None:
             side.wait_event(ev)
+        buf = self.cpu_buf[key]
+        if not isinstance(buf, torch.Tensor):     # the library's pinned pool: hipMemcpyAsync on the load stream through the C ABI
+            from ... import _native as _n
+            _n.copy_h2d_async(slot.data_ptr(), buf.ptr, slot.numel() * slot.element_size(), side.cuda_stream)
+            slot.record_stream(side)
+            return slot
         with torch.cuda.stream(side):
-            slot.copy_(self.cpu_buf[key][: slot.numel()].as_strided(shape, stride), non_blocking=True)
+            slot.copy_(buf[: slot.numel()].as_strided(shape, stride), non_blocking=True)
             slot.record_stream(side)
         return slot
 

@@ -114,7 +114,7 @@ int chipmunk_dense_colsum_topk_mask_strided(const void *q, const void *k, const 
  *   cs[b,h,g,j] = sum_{i in group g} bf16(exp(s_ij - m_i)) * bf16(exp(m_i) * p_i)   for j < Nk
  * (dense_colsum_attn.cu:267-277); columns j >= Nk are left untouched.
  * Launches that fill the CUs run as ONE pass (the column sums ride the dense kernel's softmax pipeline) and keep, per
- * (device, stream), a library-owned buffer of bf16 partial sums of B*H*ceil(Nq/256)*4*Nk*2 bytes (halved per chunk of
+ * (device, stream), a library-owned buffer of bf16 partial sums of B*H*ceil(Nq/256)*2*Nk*2 bytes (halved per chunk of
  * heads if that cannot be allocated; bounded, see chipmunk_release_scratch); the first call on a stream allocates it, so call
  * once before capturing a graph. */
 int chipmunk_dense_colsum_attn(const void *q, const void *k, const void *v, const int64_t q_strides[3],
@@ -265,6 +265,20 @@ int chipmunk_bitunpack(const void *packed, void *mask, int64_t n, void *stream);
  * (src/chipmunk/ops/voxel.py:9-99) -- whose permutations the host side computes once per shape. `map` int32 [n_out]. */
 int chipmunk_gather_rows(const void *src, void *dst, const int32_t *map, int64_t outer, int64_t n_src, int64_t n_out,
                          int64_t row_bytes, void *stream);
+
+/* ---------------------------------------------------------------- pinned host offload pool
+ * Replaces the reference's per-layer pinned CPU buffers and its two module-level CUDA streams' copies
+ * (src/chipmunk/util/storage/offloaded_tensor.py:12-13 the streams, :42-44,71 `torch.empty(..., pin_memory=True)`, :104-118 and
+ * :140-160 `copy_(non_blocking=True)`): hipHostMalloc'd buffers owned by the library and hipMemcpyAsync on the caller's side stream.
+ * chipmunk_host_alloc: page-locked host memory (hipHostMallocDefault); chipmunk_host_free gives it back (the caller makes sure no copy
+ * on it is in flight).  chipmunk_copy_d2h_async / _h2d_async: one hipMemcpyAsync of `bytes` contiguous bytes on `stream` (a dense
+ * permuted tensor travels as its storage); ordering against other streams is the caller's (events), as in the reference.
+ * chipmunk_host_bytes: bytes currently allocated through chipmunk_host_alloc (diagnostic). */
+int chipmunk_host_alloc(size_t bytes, void **host_ptr);
+int chipmunk_host_free(void *host_ptr);
+int chipmunk_copy_d2h_async(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int chipmunk_copy_h2d_async(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+size_t chipmunk_host_bytes(void);
 
 /* Gives back the library's device scratch (work plans, split partials, the multi-GB partial column sums of the fused
  * dense_colsum_attn pass -- bounded by option "big_scratch_gb", default 24).  Synchronises the device. */

@@ -147,3 +147,60 @@ def test_two_compute_streams_each_see_their_loaded_values(cfg):
                 h.load_async(); h.load_async_wait()
                 got = h.get_loaded_value()
                 assert torch.equal(got, b + rnd), f"round {rnd}: {h.name} read back stale data on its own compute stream"
+
+
+def test_native_pinned_pool_is_the_default_and_torch_pinned_tensors_the_fallback(cfg):
+    """Round 6: the pinned side of the offload is the LIBRARY's pool (chipmunk_host_alloc = hipHostMalloc, chipmunk_copy_*_async =
+    hipMemcpyAsync on the side streams; north_star wording, reference offloaded_tensor.py:42-44,71,104-118).  Same round trip with the
+    key on (default) and off (torch pinned tensors); a dense permuted (token-major) tensor travels as its storage either way."""
+    from chipmunk_amd import _native
+    from chipmunk_amd.util.storage import MaybeOffloadedTensor
+    cfg["offloading"]["global_disable_offloading"] = False
+    cfg["offloading"]["attn.out_cache"] = True
+    dev = torch.device("cuda:0")
+    base = torch.randn(1, 640, 6, 128, device=dev).to(torch.bfloat16)
+    tm = base.permute(0, 2, 1, 3)                       # [B, H, N, D] view of [B, N, H, D] storage
+    before = _native.host_bytes()
+    for native in (True, False):
+        cfg["offloading"]["native_host_pool"] = native
+        t = MaybeOffloadedTensor("attn.out_cache", 0, torch.bfloat16, dev)
+        t.offload(tm)
+        buf = t.cpu_buf[0]
+        assert isinstance(buf, _native.HostBuffer) == native and buf.is_pinned() and buf.numel() == tm.numel()
+        t.load_async(); t.load_async_wait()
+        got = t.get_loaded_value()
+        assert got.stride() == tm.stride() and torch.equal(got, tm)
+        if native:
+            assert _native.host_bytes() == before + tm.numel() * 2
+            t.cpu_buf[0] = None
+            del buf
+            import gc
+            gc.collect()
+            assert _native.host_bytes() == before, "a dropped HostBuffer gives its pages back"
+
+
+def test_host_pool_c_abi_called_directly():
+    """chipmunk_host_alloc / chipmunk_copy_d2h_async / chipmunk_copy_h2d_async / chipmunk_host_free through ctypes, no torch types in the
+    signatures: device -> pinned host -> device round trip on a side stream, bit for bit; errors come back as return codes."""
+    import ctypes
+    import chipmunk_amd  # noqa: F401
+    from chipmunk_amd import _native
+    lib = _native.lib()
+    dev = torch.device("cuda:0")
+    src = torch.randn(1 << 20, device=dev)
+    dst = torch.zeros_like(src)
+    nbytes = src.numel() * 4
+    p = ctypes.c_void_p()
+    assert lib.chipmunk_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p)) == 0 and p.value
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    st = ctypes.c_void_p(s.cuda_stream)
+    assert lib.chipmunk_copy_d2h_async(p, ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(nbytes), st) == 0
+    assert lib.chipmunk_copy_h2d_async(ctypes.c_void_p(dst.data_ptr()), p, ctypes.c_size_t(nbytes), st) == 0
+    s.synchronize()
+    assert torch.equal(src, dst)
+    host = (ctypes.c_float * 4).from_address(p.value)
+    assert list(host) == src[:4].cpu().tolist()
+    assert lib.chipmunk_host_free(p) == 0
+    assert lib.chipmunk_host_free(ctypes.c_void_p(0x1000)) != 0 and b"not allocated" in lib.chipmunk_last_error()
+    assert lib.chipmunk_host_alloc(ctypes.c_size_t(0), ctypes.byref(p)) != 0
