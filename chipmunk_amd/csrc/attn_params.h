@@ -21,6 +21,8 @@ struct AttnParams {
     float o_scale;
     // key-split tail (see launch_attn): items >= split_full are handed to `nsplit` workgroups, each over a slice of the
     // item's key tiles; partial (o, m, l) go through `ws`, the last arriver (ticket) merges and runs the epilogue
+    // (row-split tail, attn.hip MIX: split_full = the first item that runs as three 64-row workgroups, nsplit = 0; work-balanced launch,
+    // BAL: tickets + 4096.. hold its id counter and flags, ws its published states)
     int split_full, nsplit;
     float *ws;
     int32_t *tickets;
