@@ -17,7 +17,7 @@ extern "C" int chipmunk_abi_version(void) { return 1; }
 #include <string.h>
 namespace {
 struct Option { const char *name; int value; };
-Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"attn_no_tail", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}, {"attn_fused_colsum", 0}, {"attn_cs_probe", 0}, {"big_scratch_gb", 0}, {"attn_balanced", 0}, {"attn_row_split", 0}};
+Option g_options[] = {{"mm1_variant", 0}, {"mm2_variant", 0}, {"attn_variant", 0}, {"m2i_variant", 0}, {"topk_variant", 0}, {"mm1_nr", 0}, {"mm2_nr", 0}, {"mm1_probe", 0}, {"attn_xcd_chunks", 0}, {"attn_no_order", 0}, {"attn_no_tail", 0}, {"mm1_no_split", 0}, {"mm2_no_split", 0}, {"attn_no_split", 0}, {"attn_split_gather", 0}, {"attn_pp", 0}, {"attn_dense64", 0}, {"attn_csp64", 0}, {"attn_colsum64", 0}, {"attn_csp96", 0}, {"attn_nomax", 0}, {"attn_fused_colsum", 0}, {"attn_cs_probe", 0}, {"big_scratch_gb", 0}, {"attn_balanced", 0}, {"attn_row_split", 0}, {"mm2_order", 0}};
 }
 int chipmunk_get_option(const char *name) {
     for (auto &o : g_options) if (strcmp(o.name, name) == 0) return o.value;

@@ -522,6 +522,7 @@ struct Mm2Params {
     uint16_t *c;            // [M,N2], accumulated in place
     const int32_t *indices, *counts;
     int M, F, N2, NT, NR, probe;
+    int cus_per_xcd;   // > 0: length-aware placement of a one-round launch (see mm2_kernel), 0: dispatch order = tile order
 };
 
 template <int BN, int BK, int NST, int WPS, int NW = 4>
@@ -546,8 +547,36 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256, WPS) void mm2_kernel(const Mm2
     const int xcdq = (G * p.NT) >> 3, xcdr = (G * p.NT) & 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     if (slot >= xcdq + (xcd < xcdr ? 1 : 0)) return;
-    const int t = (xcd < xcdr ? xcd * (xcdq + 1) : xcdr * (xcdq + 1) + (xcd - xcdr) * xcdq) + slot;
     const int NR = p.NR;
+    const int mine = xcdq + (xcd < xcdr ? 1 : 0);
+    const int tbase = xcd < xcdr ? xcd * (xcdq + 1) : xcdr * (xcdq + 1) + (xcd - xcdr) * xcdq;
+    auto group_of = [&](int tt) {
+        const int nb_ = tt / (G * NR), rem_ = tt - nb_ * (G * NR);
+        return rem_ / min(NR, p.NT - nb_ * NR);
+    };
+    int t = tbase + slot;
+    // Length-aware placement of a ONE-ROUND launch (round 6).  A tile's k loop is as long as its group's kept count, and a launch of
+    // `mine` tiles per XCD on 2 x cus_per_xcd slots lasts as long as its slowest tile.  Workgroups reach the CUs in dispatch order
+    // (tools/probes/dispatch_census.hip: local index l lands on CU l mod cus_per_xcd, so l and l + cus share a CU and the indices
+    // [mine - cus, cus) have a CU to themselves -- observed, a speed heuristic only), and a workgroup alone on its CU runs ~25 % faster.
+    // So this XCD's tiles are ranked by length (longest first, ties by tile order) and handed out by position: the lone positions
+    // take the longest tiles, pair (l, l + cus) takes the next longest together with the shortest.  Same tiles per XCD (same L2
+    // working set), same arithmetic per tile: only who computes what moves.
+    const int cap = p.cus_per_xcd;
+    if (cap > 0 && mine > cap && mine <= 64 && mine <= 2 * cap) {
+        const int nl = 2 * cap - mine;                      // lone positions: [mine - cap, cap)
+        const int want = slot < mine - cap ? nl + slot      // first member of a pair: the longest of what the lone ones left
+                         : slot < cap      ? slot - (mine - cap)   // alone on its CU: the longest of all
+                                           : mine - 1 - (slot - cap);   // second member (partner of slot - cap): the shortest
+        const int len = lane < mine ? p.counts[group_of(tbase + lane)] : -1;
+        int rank = 0;
+        for (int j = 0; j < mine; ++j) {
+            const int lj = __shfl(len, j);
+            rank += (lj > len || (lj == len && j < lane)) ? 1 : 0;
+        }
+        const unsigned long long hit = __ballot(lane < mine && rank == want);
+        t = tbase + (int)__builtin_ctzll(hit);
+    }
     const int nb = t / (G * NR), rem = t - nb * (G * NR);
     const int nr = min(NR, p.NT - nb * NR);
     const int g = rem / nr, nt = nb * NR + rem - g * nr;
@@ -876,6 +905,8 @@ int launch_mm2_variant(const Mm2Params &p0, hipStream_t s) {
     p.NT = (p.N2 + BN - 1) / BN;
     p.NR = chipmunk_get_option("mm2_nr") > 0 ? chipmunk_get_option("mm2_nr") : 4;
     if (p.NR > p.NT) p.NR = p.NT;
+    // length-aware placement: two-workgroups-per-CU forms only (what the census measured); option mm2_order = 1 keeps tile order
+    p.cus_per_xcd = (WPS == 2 && !chipmunk_get_option("mm2_order")) ? device_cu_count() / 8 : 0;
     hipLaunchKernelGGL(kern, dim3((((p.M / BM) * p.NT + 7) / 8) * 8), dim3(NW * 64), LDS, s, p);
     CM_LAUNCH_CHECK();
     return CHIPMUNK_OK;
