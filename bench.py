@@ -274,15 +274,16 @@ def build_flux(dev, n_layers, timer, whole_block=True):
         the hidden state for their cost; attention consumes the synthetic q, k, v and the image-token MLP the slowly drifting synthetic
         input of the core step (so the |delta| top-k sees realistic column statistics); their outputs feed the block's residuals."""
         with torch.no_grad():
-            x = (x_state[:512], x_state[512:])
-            for attn, mlp, (q, k, v, xs), fc1, fc2, act, blk in layers:
+            x, xm = (x_state[:512], x_state[512:]), None
+            for li, (attn, mlp, (q, k, v, xs), fc1, fc2, act, blk) in enumerate(layers):
                 if blk.kind == "single" and isinstance(x, tuple):
-                    x = torch.cat(x, 0)
-                blk.pre(x)
+                    x, xm = torch.cat(x, 0), None
+                blk.pre(x, xm)
                 o = torch.nn.functional.scaled_dot_product_attention(q, k, v) if dense else attn(q, k, v)
                 xin = xs[i % NX]
                 mlp_fn = (lambda _xm: dense_mlp(xin, fc1, fc2)[0]) if dense else (lambda _xm: mlp(xin)[0])
-                x = blk.post(x, o, mlp_fn)
+                nb = layers[li + 1][6] if li + 1 < len(layers) else None
+                x, xm = blk.post(x, o, mlp_fn, nb.first_mod() if nb is not None and nb.kind == blk.kind else None)
 
     step = block_step if whole_block else core_step
     dense_step = (lambda i: block_step(i, dense=True)) if whole_block else core_dense_step
@@ -516,37 +517,48 @@ class FluxBlock:
                                                               ang.sin().repeat_interleave(2, dim=1).contiguous())
         ops_pkg.qkv_split_norm(h, self.qk_w[0], self.qk_w[1], self.heads, 1e-6, rope[0], rope[1])
 
-    def pre(self, x):
+    def first_mod(self):
+        """(shift, scale) pairs of the LayerNorm + modulate this block opens with (double: (image, text)): the previous block's closing gated
+        residual takes them along, as in the HunyuanVideo block (one row-wise pass instead of an addcmul and a norm pass)."""
+        return ((self.mod[0], self.mod[1]), (self.t_mod[0], self.t_mod[1])) if self.kind == "double" else ((self.mod[0], self.mod[1]),)
+
+    def pre(self, x, xm=None):
         """x: double-stream (txt [512, hid], img [3840, hid]); single-stream [L, hid], text rows first (the reference concatenates
-        (txt, img), :174-176 and model.py's `img = torch.cat((txt, img), 1)` between the two kinds of block)."""
+        (txt, img), :174-176 and model.py's `img = torch.cat((txt, img), 1)` between the two kinds of block).  xm: the opening LayerNorm +
+        modulate of x (same structure) if the previous block's closing pass produced it."""
         nt = self.n_txt
         if self.kind == "double":
             txt, img = x
-            xm = HunyuanBlock._ln_mod(img, self.mod[0], self.mod[1])
-            torch.addmm(self.qkv.bias, xm, self.qkv.weight.t(), out=self.qkv_buf[nt:])
-            tm = HunyuanBlock._ln_mod(txt, self.t_mod[0], self.t_mod[1])
+            im, tm = xm if xm is not None else (None, None)
+            if im is None:
+                im = HunyuanBlock._ln_mod(img, self.mod[0], self.mod[1])
+            torch.addmm(self.qkv.bias, im, self.qkv.weight.t(), out=self.qkv_buf[nt:])
+            if tm is None:
+                tm = HunyuanBlock._ln_mod(txt, self.t_mod[0], self.t_mod[1])
             torch.addmm(self.t_qkv.bias, tm, self.t_qkv.weight.t(), out=self.qkv_buf[:nt])
         else:
-            xm = HunyuanBlock._ln_mod(x, self.mod[0], self.mod[1])
+            if xm is None:
+                xm = HunyuanBlock._ln_mod(x, self.mod[0], self.mod[1])
             torch.addmm(self.qkv.bias, xm, self.qkv.weight.t(), out=self.qkv_buf)
         self._split_norm_rope()
 
-    def post(self, x, attn, mlp_fn):
-        """attn: [1, H, L, D]; mlp_fn(rows) -> the image-row (double) / all-row (single) MLP output [rows, hid], sparse or dense."""
+    def post(self, x, attn, mlp_fn, nxt=None):
+        """attn: [1, H, L, D]; mlp_fn(rows) -> the image-row (double) / all-row (single) MLP output [rows, hid], sparse or dense; nxt: first_mod()
+        of the NEXT block when it is of the same kind (None otherwise / after the last).  Returns (x, xm for the next block | None)."""
         hid, nt = self.hid, self.n_txt
         a = attn[0].permute(1, 0, 2).reshape(attn.shape[2], hid)               # the reference's rearrange before the projections
         if self.kind == "double":
             txt, img = x
             img, xm2 = HunyuanBlock._res_ln_mod(img, self.mod[2], torch.addmm(self.proj.bias, a[nt:], self.proj.weight.t()),
                                                 (self.mod[3], self.mod[4]))
-            img = torch.addcmul(img, self.mod[5], mlp_fn(xm2))
+            img, im_n = HunyuanBlock._res_ln_mod(img, self.mod[5], mlp_fn(xm2), nxt[0] if nxt else None)
             txt, tm2 = HunyuanBlock._res_ln_mod(txt, self.t_mod[2], torch.addmm(self.t_proj.bias, a[:nt], self.t_proj.weight.t()),
                                                 (self.t_mod[3], self.t_mod[4]))
-            txt = torch.addcmul(txt, self.t_mod[5], dense_mlp(tm2, self.t_fc1, self.t_fc2))
-            return (txt, img)
+            txt, tm_n = HunyuanBlock._res_ln_mod(txt, self.t_mod[5], dense_mlp(tm2, self.t_fc1, self.t_fc2), nxt[1] if nxt else None)
+            return (txt, img), ((im_n, tm_n) if nxt else None)
         y = torch.addmm(self.proj.bias, a, self.proj.weight.t())
         y.add_(mlp_fn(None))
-        return torch.addcmul(x, self.mod[2], y)
+        return HunyuanBlock._res_ln_mod(x, self.mod[2], y, nxt[0] if nxt else None)
 
 
 def sdpa_backend_name():
