@@ -1131,7 +1131,10 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
         }
     }
     // Work-balanced launch (BAL, see attn_kernel): gathered launches of a few rounds whose last round would be poorly filled.
-    // Option attn_balanced: 1 = always (tests), 3 = by shape, 0 / 2 = never (measured slower than the two-round launch so far, see DESIGN).
+    // Option attn_balanced: 1 = always (tests), 3 = by shape, 0 / 2 = never.  NOT in the product library (round 6): the row-split tail below
+    // beats it wherever the host can tell the two apart (21 and 42 tiles per item; it is 2-3 % ahead at 84), and the host does not know the
+    // counts.  tools/probes/mm1_forms/build.sh compiles it in (-DCHIPMUNK_ATTN_PROBES) and its tests run against that library.
+#ifdef CHIPMUNK_ATTN_PROBES
     if constexpr (GATHER && !CSONLY && !WRITE_L) {
         const int ob = chipmunk_get_option("attn_balanced");
         const int64_t slots = wg_per_cu * (int64_t)device_cu_count();
@@ -1152,15 +1155,17 @@ int launch_attn(const AttnParams &p, hipStream_t stream) {
             }
         }
     }
+#endif
     // Row-split tail (MIX, see attn_kernel): the last `nblocks mod slots` items of a gathered launch of at least one full round run as
-    // three 64-row workgroups each, when that many thirds fit the slots.  Option attn_row_split: 0 = by shape, 1 = always (the last
-    // min(nblocks, slots / 3) items; tests), 2 = never.
+    // three 64-row workgroups each, when the thirds get a CU each (3 x rem <= slots / 2: a third is cheap alone on its CU, not when paired --
+    // 644 items, 132 in the tail: 72.0 vs 67.5 us for the plain-output form with the looser 3 x rem <= slots).  Option attn_row_split:
+    // 0 = by shape, 1 = always (the last min(nblocks, slots / 3) items; tests), 2 = never.
     if constexpr (GATHER && !CSONLY && !WRITE_L) {
         const int orow = chipmunk_get_option("attn_row_split");
         const int64_t slots = wg_per_cu * (int64_t)device_cu_count();
         int64_t rem = nblocks > slots ? nblocks % slots : 0;
         if (orow == 1) rem = nblocks < slots / 3 ? nblocks : slots / 3;
-        if (!pp.plan && !pp.xcd_chunks && orow != 2 && rem > 0 && rem * 3 <= slots) {
+        if (!pp.plan && !pp.xcd_chunks && orow != 2 && rem > 0 && (orow == 1 ? rem * 3 <= slots : rem * 6 <= slots)) {
             auto km = attn_kernel<GATHER, INPLACE, WRITE_L, CSONLY, false, true>;
             static uint64_t lds_set_m = 0;
             ensure_dynamic_lds((const void *)km, ATTN_LDS_BYTES, lds_set_m);

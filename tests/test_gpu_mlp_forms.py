@@ -1,6 +1,6 @@
-"""The GEMM1 / GEMM2 forms that were measured against the shipped kernels and live outside the product library
-(tools/probes/mm1_forms: tile shapes, the two producer / consumer GEMM1 forms) stay parity-tested: when
-tools/bin/forms/libchipmunk_hip.so has been built (tools/probes/mm1_forms/build.sh), the MLP parity files run once more in a
+"""The forms that were measured against the shipped kernels and live outside the product library (tools/probes/mm1_forms: GEMM tile
+shapes, the two producer / consumer GEMM1 forms, the work-balanced gathered attention launch) stay parity-tested: when
+tools/bin/forms/libchipmunk_hip.so has been built (tools/probes/mm1_forms/build.sh), the MLP parity files and the balanced-launch tests run in a
 subprocess bound to that library with every form enabled.  Skipped when the forms library is absent (it is not part of build())."""
 import os
 import subprocess
@@ -18,7 +18,8 @@ FORMS = os.path.join(ROOT, "tools", "bin", "forms", "libchipmunk_hip.so")
 def test_probe_forms_pass_the_mlp_parity_suite():
     env = dict(os.environ, CHIPMUNK_MM1_FORMS="1", CHIPMUNK_HIP_LIB=FORMS,
                LD_LIBRARY_PATH=os.path.dirname(FORMS) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_mlp.py", "tests/test_gpu_mlp_bench_shape.py"],
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_mlp.py", "tests/test_gpu_mlp_bench_shape.py",
+                        "tests/test_gpu_attn_forms_balanced.py"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

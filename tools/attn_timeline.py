@@ -16,7 +16,7 @@ LIB = os.path.join(ROOT, "tools", "bin", "libchipmunk_tl.so")
 def build():
     src = [os.path.join(ROOT, "chipmunk_amd", "csrc", f) for f in ("attn.hip", "attn64.hip", "attn96.hip", "mlp.hip", "indexed_io.hip", "rowwise.hip", "capi.hip")]
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DATTN_TIMELINE", "-o", LIB] + src)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DATTN_TIMELINE", "-DCHIPMUNK_ATTN_PROBES", "-o", LIB] + src)
 
 
 def pct(xs, p):

@@ -1,6 +1,7 @@
 """Hand-off soak of the work-balanced gathered launch (attn.hip, BAL) under UNEVEN load: a second stream keeps the CUs busy with GEMMs of
 varying size while the balanced launch runs; every launch must give the plain launch's bits (a continued item is the uncut item's own
-arithmetic).  Also soaks the row-split tail (run-to-run identity).  usage: python tools/probes/bal_soak.py [launches]"""
+arithmetic).  Also soaks the row-split tail (run-to-run identity).  usage (probe-forms library, tools/probes/mm1_forms/build.sh):
+  LD_LIBRARY_PATH=tools/bin/forms CHIPMUNK_HIP_LIB=$PWD/tools/bin/forms/libchipmunk_hip.so python tools/probes/bal_soak.py [launches]"""
 import os
 import sys
 
